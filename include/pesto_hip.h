@@ -1,0 +1,105 @@
+/* pesto_hip.h - C ABI of libpesto_hip.so: PeSTo's geometric-transformer forward pass on MI355X (gfx950).
+ *
+ * The reference has NO native/FFI layer: its operator API for this path is the torch Module
+ *     Model(config_model).load_state_dict(...); z = model(X, ids_topk, q0, M)
+ * (reference model/model.py:7-52; call sites apply_model.ipynb:87-93,155, profiling.py:24-28,102,
+ * interfaceome/apply_model.py:33-34,73).  Each entry point below names the reference interface it
+ * replaces.  Plain pointers and sizes only; no torch types.  All functions return 0 on success and a
+ * negative pesto_status on failure; pesto_last_error() gives the thread-local message.
+ *
+ * Conventions (identical to the reference tensors):
+ *   X          float32 [N,3]        atom coordinates of the collated batch
+ *   ids_topk   int64 or int32 [N,k] 1-based neighbour ids into the sink-augmented arrays, 0 = sink /
+ *                                   padding, columns in ascending distance (k <= 64)
+ *   q0         float32 [N,n0]       input features (one-hot in practice, any values accepted)
+ *   res_of_atom int32 [N]           residue (column of the reference's mask M) each atom belongs to;
+ *                                   the host layer derives it from M (exactly one 1 per row)
+ *   z          float32 [R,n_out]    logits per residue
+ */
+#ifndef PESTO_HIP_H
+#define PESTO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PESTO_MAX_LAYERS 64
+#define PESTO_MAX_K 64
+
+typedef enum pesto_status {
+    PESTO_OK = 0,
+    PESTO_ERR_INVALID = -1,   /* bad argument / config / blob size */
+    PESTO_ERR_HIP = -2,       /* a HIP runtime call failed */
+    PESTO_ERR_NOMEM = -3,
+    PESTO_ERR_STATE = -4      /* debug entry point called out of order */
+} pesto_status;
+
+/* replaces: the config dict consumed by Model.__init__ (model/model.py:7-30, model/config.py:25-63).
+ * Ns=32, Nh=2, Nk=3, pool Nh=4, N1=32 are fixed (true for every run shipped with the reference). */
+typedef struct pesto_config {
+    int32_t n0;                    /* config["em"]["N0"]: 30 (i_v4_*) or 123 (i_v3_*) */
+    int32_t n_layers;              /* len(config["sum"]) */
+    int32_t nn[PESTO_MAX_LAYERS];  /* config["sum"][l]["nn"] in {8,16,32,64} */
+    int32_t n_out;                 /* config["dm"]["N2"] */
+    int32_t em_depth;              /* 3 = Linear-ELU-Linear-ELU-Linear (model/model.py:10-16); 1 = single Linear (i_v3_1) */
+    int32_t dm_depth;              /* same for the decoder (model/model.py:24-30) */
+} pesto_config;
+
+typedef struct pesto_model pesto_model;
+
+enum { PESTO_PTR_HOST = 0, PESTO_PTR_DEVICE = 1 };
+enum { PESTO_IDS_INT32 = 32, PESTO_IDS_INT64 = 64 };
+
+const char* pesto_last_error(void);
+
+/* number of float32 values in the weight blob for this config (schema: pesto_amd/weights.py) */
+int pesto_blob_size(const pesto_config* cfg, int64_t* n_floats);
+
+/* replaces: Model(config) + load_state_dict + .to(device)  (apply_model.ipynb:87-93).
+ * weights: HOST pointer to the flat blob (state_dict order, m_nn/sdk skipped). The library keeps its
+ * own device copy (re-laid-out for the kernels). device: HIP device ordinal. */
+int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weights, int device, pesto_model** out);
+int pesto_destroy(pesto_model* m);
+
+/* replaces: Model.forward(X, ids_topk, q0, M)  (model/model.py:32-52).
+ * ptr_kind: PESTO_PTR_HOST (library stages H2D/D2H itself) or PESTO_PTR_DEVICE (all five buffers on
+ * the model's device). stream: a hipStream_t (NULL = the model's own stream). With device pointers the
+ * call is asynchronous on `stream`; with host pointers it returns after z has been copied back.
+ * No allocation happens on this path once the grow-only workspace has seen a batch of this size. */
+int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k,
+                  const float* X, const void* ids_topk, int32_t ids_kind,
+                  const float* q0, const int32_t* res_of_atom,
+                  float* z_out, int32_t ptr_kind, void* stream);
+
+/* bytes of device workspace a batch of (N, R) needs (ownership: SURVEY 8b) */
+int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* bytes);
+
+/* wait for everything queued on the model's own stream */
+int pesto_synchronize(pesto_model* m);
+
+/* mean duration in milliseconds of the state-update kernels of the most recent pesto_forward, measured with
+ * HIP events on the stream they ran on (bench.py's roofline leg); enable with pesto_set_timing(m, 1). */
+int pesto_set_timing(pesto_model* m, int32_t enabled);
+int pesto_get_timing(pesto_model* m, double* layers_ms, double* total_ms, int32_t* n_layer_launches);
+
+/* ---- per-stage entry points (HOST pointers), used by tests/ to pin each stage against the oracle ----
+ * replaces: em.forward (model/model.py:34) */
+int pesto_stage_embed(pesto_model* m, int64_t N, const float* q0, float* q_out /*[N,32]*/);
+/* replaces: unpack_state_features (src/model_operations.py:6-22); outputs include the sink row 0 */
+int pesto_stage_unpack(pesto_model* m, int64_t N, int32_t k, const float* X, const void* ids_topk, int32_t ids_kind,
+                       float* D_out /*[N+1,k]*/, float* R_out /*[N+1,k,3]*/);
+/* replaces: StateUpdateLayer.forward (src/model_operations.py:225-242) for layer `layer`, using the geometry
+ * left by the last pesto_stage_unpack; q [N+1,32] and p [N+1,3,32] updated in place */
+int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io);
+/* replaces: StatePoolLayer.forward + decoder (src/model_operations.py:197-213, model/model.py:46-50);
+ * q [N,32], p [N,3,32] WITHOUT the sink row */
+int pesto_stage_pool(pesto_model* m, int64_t N, int64_t R, const float* q, const float* p, const int32_t* res_of_atom,
+                     float* qr_out /*[R,32]*/, float* pr_out /*[R,3,32]*/, float* z_out /*[R,n_out]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PESTO_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of libpesto_hip.so (the C ABI declared in include/pesto_hip.h).
+
+The library is built in-tree by ``python -m pesto_amd.csrc.build`` (hipcc --offload-arch=gfx950) and
+must be present: there is NO fallback path - a missing library raises at first use.
+"""
+import ctypes
+import os
+
+from .config import MAX_LAYERS, normalise
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpesto_hip.so")
+
+PTR_HOST, PTR_DEVICE = 0, 1
+IDS_INT32, IDS_INT64 = 32, 64
+
+
+class PestoConfig(ctypes.Structure):
+    """struct pesto_config (include/pesto_hip.h)."""
+    _fields_ = [
+        ("n0", ctypes.c_int32),
+        ("n_layers", ctypes.c_int32),
+        ("nn", ctypes.c_int32 * MAX_LAYERS),
+        ("n_out", ctypes.c_int32),
+        ("em_depth", ctypes.c_int32),
+        ("dm_depth", ctypes.c_int32),
+    ]
+
+
+def make_c_config(config):
+    c = normalise(config)
+    cc = PestoConfig()
+    cc.n0 = c["em"]["N0"]
+    cc.n_layers = len(c["sum"])
+    for i, l in enumerate(c["sum"]):
+        cc.nn[i] = l["nn"]
+    cc.n_out = c["dm"]["N2"]
+    cc.em_depth = c["em_depth"]
+    cc.dm_depth = c["dm_depth"]
+    return cc
+
+
+# every symbol include/pesto_hip.h declares (tests/test_abi.py checks the built library exports them all)
+ABI_SYMBOLS = [
+    "pesto_last_error", "pesto_blob_size", "pesto_create", "pesto_destroy", "pesto_forward",
+    "pesto_workspace_bytes", "pesto_synchronize", "pesto_set_timing", "pesto_get_timing",
+    "pesto_stage_embed", "pesto_stage_unpack", "pesto_stage_layer", "pesto_stage_pool",
+]
+
+_lib = None
+
+
+class PestoError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpesto_hip.so (once). Raises PestoError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PestoError(f"{LIB_PATH} not found: build it with `python -m pesto_amd.csrc.build` "
+                         "(there is no CPU/PyTorch fallback for the forward pass)")
+    lib = ctypes.CDLL(LIB_PATH)
+    c_p, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    P = ctypes.POINTER
+    lib.pesto_last_error.restype = ctypes.c_char_p
+    lib.pesto_last_error.argtypes = []
+    lib.pesto_blob_size.argtypes = [P(PestoConfig), P(i64)]
+    lib.pesto_create.argtypes = [P(PestoConfig), c_p, i64, ctypes.c_int, P(c_p)]
+    lib.pesto_destroy.argtypes = [c_p]
+    lib.pesto_forward.argtypes = [c_p, i64, i64, i32, c_p, c_p, i32, c_p, c_p, c_p, i32, c_p]
+    lib.pesto_workspace_bytes.argtypes = [c_p, i64, i64, P(i64)]
+    lib.pesto_synchronize.argtypes = [c_p]
+    lib.pesto_set_timing.argtypes = [c_p, i32]
+    lib.pesto_get_timing.argtypes = [c_p, P(ctypes.c_double), P(ctypes.c_double), P(i32)]
+    lib.pesto_stage_embed.argtypes = [c_p, i64, c_p, c_p]
+    lib.pesto_stage_unpack.argtypes = [c_p, i64, i32, c_p, c_p, i32, c_p, c_p]
+    lib.pesto_stage_layer.argtypes = [c_p, i32, c_p, c_p]
+    lib.pesto_stage_pool.argtypes = [c_p, i64, i64, c_p, c_p, c_p, c_p, c_p, c_p]
+    for name in ABI_SYMBOLS:
+        if name != "pesto_last_error":
+            getattr(lib, name).restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().pesto_last_error()
+        raise PestoError(f"libpesto_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,56 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def onehot(idx, n0):
+    """q_idx [N, 1 or 3] -> dense one-hot float32 [N, n0] (element | resname | atom-name blocks)."""
+    idx = np.asarray(idx, dtype=np.int64)
+    q = np.zeros((idx.shape[0], n0), np.float32)
+    offs = [0, 30, 59]
+    for c in range(idx.shape[1]):
+        q[np.arange(idx.shape[0]), offs[c] + idx[:, c]] = 1.0
+    return q
+
+
+_weights_cache = {}
+
+
+def weights(tag):
+    """state_dict (numpy) for a fixture tag: real i_v4_0/i_v3_0/i_v3_1, or i_v4_1 = stacked i_v4_0."""
+    if tag not in _weights_cache:
+        from pesto_amd.config import CONFIGS
+        from pesto_amd.weights import stack_layers
+        if tag == "i_v4_1":
+            _weights_cache[tag] = stack_layers(weights("i_v4_0"), CONFIGS["i_v4_1"], 0.5)
+        elif tag == "i_v3_1":  # hybrid: own em/dm + i_v3_0 sum/spl (see tests/golden/make_golden.py)
+            sd = dict(weights("i_v3_0"))
+            d = golden("weights_i_v3_1_emdm")
+            sd = {k: v for k, v in sd.items() if not k.startswith(("em.", "dm."))}
+            sd.update({k: d[k] for k in d.files})
+            _weights_cache[tag] = sd
+        else:
+            d = golden("weights_" + tag)
+            _weights_cache[tag] = {k: d[k] for k in d.files}
+    return _weights_cache[tag]
+
+
+@pytest.fixture(scope="session")
+def gpu_available():
+    import torch
+    return torch.cuda.is_available()

@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by IMPORTING the
+reference PyTorch CPU path from /root/reference (build container only).
+
+The reference python never leaves this container: what is committed is DATA
+(inputs, weights-as-arrays, expected outputs) plus this script.  Nothing under
+tests/, bench.py or __graft_entry__.py reads /root/reference at run time.
+
+Reference entry points exercised (file:line relative to /root/reference):
+  model/model.py:32-52              Model.forward  (whole-forward goldens)
+  src/model_operations.py:6-22      unpack_state_features  (op golden)
+  src/model_operations.py:225-242   StateUpdateLayer.forward (op goldens, nn=8/16/32/64)
+  src/model_operations.py:197-213   StatePoolLayer.forward  (op golden)
+  src/data_encoding.py:61-102       encode_structure / encode_features / extract_topology
+  src/dataset.py:91-112             collate_batch_features
+
+Usage:  python tests/golden/make_golden.py        (takes a few minutes on 8 cores)
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch as pt
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+warnings.filterwarnings("ignore")
+pt.manual_seed(0)
+
+
+def import_reference(run):
+    """Mirror apply_model.ipynb:67-73: put the saved run first on sys.path, then the repo root."""
+    for m in ("config", "model"):
+        sys.modules.pop(m, None)
+    save_path = os.path.join(REF, "model", "save", run)
+    sys.path = [p for p in sys.path if "/model/save/" not in p]
+    sys.path.insert(0, save_path)
+    if REF not in sys.path:
+        sys.path.insert(1, REF)
+    if "gemmi" not in sys.modules:  # src/structure_io.py:1 imports gemmi (absent here); never called
+        g = types.ModuleType("gemmi")
+        g.cif = types.ModuleType("gemmi.cif")
+        sys.modules["gemmi"] = g
+        sys.modules["gemmi.cif"] = g.cif
+    from config import config_model
+    from model import Model
+    return config_model, Model, save_path
+
+
+def load_run(run, ckpt="model_ckpt.pt"):
+    config_model, Model, save_path = import_reference(run)
+    model = Model(config_model)
+    sd = pt.load(os.path.join(save_path, ckpt), map_location="cpu")
+    print(run, model.load_state_dict(sd))
+    return config_model, model.eval()
+
+
+def parse_pdb(path):
+    """Fixed-column reader for the already-cleaned single-model heavy-atom files under
+    pdbs_test/ and examples/ (columns as written by src/structure_io.py:118)."""
+    name, resname, resid, xyz, element, chain = [], [], [], [], [], []
+    for line in open(path):
+        if not (line.startswith("ATOM") or line.startswith("HETATM")):
+            continue
+        name.append(line[12:16].strip())
+        resname.append(line[17:20].strip())
+        chain.append(line[21])
+        resid.append(int(line[22:26]))
+        xyz.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+        element.append(line[76:78].strip().capitalize())
+    structure = {
+        "xyz": np.array(xyz, dtype=np.float32),
+        "name": np.array(name),
+        "element": np.array(element),
+        "resname": np.array(resname),
+        "resid": np.array(resid, dtype=np.int32),
+        "chain_name": np.array(chain),
+    }
+    # renumber residues contiguously the way clean_structure does (src/structure.py:33-50)
+    d_chain = np.concatenate([[0], (structure["chain_name"][1:] != structure["chain_name"][:-1]).astype(int)])
+    d_res = np.abs(np.sign(np.concatenate([[0], np.diff(structure["resid"])])))
+    structure["resid"] = (np.cumsum(np.sign(d_chain + d_res)) + 1).astype(np.int64)
+    return structure
+
+
+def encode(structure, all_features):
+    """apply_model.ipynb:141-152 (reference functions, imported)."""
+    from src.data_encoding import encode_structure, encode_features, extract_topology
+    X, M = encode_structure(structure)
+    qs = encode_features(structure)
+    q = pt.cat(qs, dim=1) if all_features else qs[0]
+    ids_topk = extract_topology(X, 64)[0]
+    return X, ids_topk, q, M
+
+
+def collate(items):
+    from src.dataset import collate_batch_features
+    return collate_batch_features(items)
+
+
+def onehot_to_idx(q, all_features):
+    q = q.numpy()
+    if all_features:
+        return np.stack([q[:, :30].argmax(1), q[:, 30:59].argmax(1), q[:, 59:].argmax(1)], 1).astype(np.int16)
+    return q.argmax(1).astype(np.int16)[:, None]
+
+
+def res_of_atom(M):
+    M = M.numpy()
+    assert np.all(M.sum(1) == 1)
+    return M.argmax(1).astype(np.int32)
+
+
+def sd_arrays(model):
+    return {k: v.detach().numpy() for k, v in model.state_dict().items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def synth_inputs(n, seed, n0=30):
+    """Synthetic structure from the package's seeded generator (so bench/tests can rebuild the same
+    cloud from the seed); topology from the REFERENCE's extract_topology."""
+    from src.data_encoding import extract_topology
+    from pesto_amd.topology import synthetic_structure
+    X, _, q, M = synthetic_structure(n, seed, n0=n0)
+    X = pt.from_numpy(X)
+    return X, extract_topology(X, 64)[0], pt.from_numpy(q), pt.from_numpy(M)
+
+
+def run_forward(model, X, ids, q, M):
+    with pt.no_grad():
+        return model(X, ids, q, M.float()).numpy()
+
+
+def main():
+    # ------------------------------------------------------------------ weights (real, as arrays)
+    models = {}
+    for tag, run in (("i_v4_0", "i_v4_0_2021-09-07_11-20"), ("i_v3_0", "i_v3_0_2021-05-27_14-27"),
+                     ("i_v3_1", "i_v3_1_2021-05-28_12-40")):
+        cfg, model = load_run(run)
+        if tag == "i_v3_1":
+            # The trained i_v3_1 is numerically chaotic on these inputs: the REFERENCE's own fp32 and fp64 runs
+            # differ by 10.9 on z (states reach 4e5), so it cannot anchor a 1e-4 parity test. Its ARCHITECTURE
+            # (single-Linear em and dm, model/save/i_v3_1_*/model.py:10-22) is pinned with a hybrid instead:
+            # i_v3_1's own em/dm weights + i_v3_0's sum/spl weights (same shapes; reference fp32 vs fp64: 7e-7).
+            sd30 = models["i_v3_0"][1].state_dict()
+            sd = {k: (sd30[k] if k.startswith(("sum.", "spl.")) else v) for k, v in model.state_dict().items()}
+            print("i_v3_1 hybrid", model.load_state_dict(sd))
+            save("weights_i_v3_1_emdm", **{k: v for k, v in sd_arrays(model).items() if k.startswith(("em.", "dm."))})
+            models[tag] = (cfg, model)
+            continue
+        models[tag] = (cfg, model)
+        save("weights_" + tag, **sd_arrays(model))
+
+    pdb_2ayo = parse_pdb(os.path.join(REF, "pdbs_test", "AY_2AYO_1_A:0.pdb"))
+    pdb_2cua = parse_pdb(os.path.join(REF, "examples", "issue_19_04_2023", "2CUA_A.pdb"))
+    print("2AYO atoms", pdb_2ayo["xyz"].shape[0], "2CUA atoms", pdb_2cua["xyz"].shape[0])
+
+    # ------------------------------------------------------------------ whole-forward, real weights, real geometry
+    for tag in ("i_v4_0", "i_v3_0", "i_v3_1"):
+        cfg, model = models[tag]
+        import_reference({"i_v4_0": "i_v4_0_2021-09-07_11-20", "i_v3_0": "i_v3_0_2021-05-27_14-27",
+                          "i_v3_1": "i_v3_1_2021-05-28_12-40"}[tag])
+        allf = cfg["em"]["N0"] == 123
+        for pname, st in (("2AYO", pdb_2ayo), ("2CUA", pdb_2cua)):
+            if tag != "i_v4_0" and pname == "2AYO":
+                continue  # keep the CPU suite short: 2AYO only with i_v4_0
+            X, ids, q, M = encode(st, allf)
+            Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+            z = run_forward(model, Xc, idsc, qc, Mc)
+            save(f"fwd_{tag}{'h' if tag == 'i_v3_1' else ''}_{pname}", X=Xc.numpy(), ids_topk=idsc.numpy().astype(np.int32),
+                 q_idx=onehot_to_idx(qc, allf), res_of_atom=res_of_atom(Mc), z=z)
+
+    cfg40, m40 = models["i_v4_0"]
+    import_reference("i_v4_0_2021-09-07_11-20")
+
+    # ------------------------------------------------------------------ per-op goldens on a 200-atom crop of 2CUA
+    crop = {k: v[:200] for k, v in pdb_2cua.items()}
+    X, ids, q, M = encode(crop, False)
+    Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+    from src.model_operations import unpack_state_features
+    rec = {}
+    with pt.no_grad():
+        q1 = m40.em(qc)
+        rec["em_in_idx"] = onehot_to_idx(qc, False)
+        rec["em_out"] = q1.numpy()
+        qs, ids_s, D, R = unpack_state_features(Xc, idsc, q1)
+        rec.update(X=Xc.numpy(), ids_topk=idsc.numpy().astype(np.int32), D_nn=D.numpy(), R_nn=R.numpy())
+        p = pt.zeros((qs.shape[0], 3, qs.shape[1]))
+        state = (qs, p, ids_s, D, R)
+        for li, layer in enumerate(m40.sum):
+            if li in (0, 3, 4, 8, 12, 15):
+                rec[f"L{li}_q_in"] = state[0].clone().numpy()
+                rec[f"L{li}_p_in"] = state[1].clone().numpy()
+            state = layer(state)
+            state = tuple(t.detach() for t in state)
+            if li in (0, 3, 4, 8, 12, 15):
+                rec[f"L{li}_q_out"] = state[0].clone().numpy()
+                rec[f"L{li}_p_out"] = state[1].clone().numpy()
+        qa, pa = state[0], state[1]
+        qr, pr = m40.spl(qa[1:], pa[1:], Mc.float())
+        rec["pool_qr"] = qr.numpy()
+        rec["pool_pr"] = pr.numpy()
+        zr = pt.cat([qr, pt.norm(pr, dim=1)], dim=1)
+        rec["z"] = m40.dm(zr).numpy()
+        rec["res_of_atom"] = res_of_atom(Mc)
+    save("ops_i_v4_0_crop200", **rec)
+
+    # ------------------------------------------------------------------ edge cases (i_v4_0 real weights)
+    # (a) N=40 < 64: zero-padded ids -> X[-1] wrap-around (model_operations.py:8)
+    small = {k: v[:40] for k, v in pdb_2cua.items()}
+    a = encode(small, False)
+    Xc, idsc, qc, Mc = collate([list(a)])
+    save("edge_n40", X=Xc.numpy(), ids_topk=idsc.numpy().astype(np.int32), q_idx=onehot_to_idx(qc, False),
+         res_of_atom=res_of_atom(Mc), z=run_forward(m40, Xc, idsc, qc, Mc))
+    # (b) two-structure batch (N=300 + N=40), block-diagonal M, offset ids (dataset.py:102-110)
+    b0 = encode({k: v[:300] for k, v in pdb_2cua.items()}, False)
+    b1 = encode({k: v[300:340] for k, v in pdb_2cua.items()}, False)
+    Xc, idsc, qc, Mc = collate([list(b0), list(b1)])
+    save("edge_batch2", X=Xc.numpy(), ids_topk=idsc.numpy().astype(np.int32), q_idx=onehot_to_idx(qc, False),
+         res_of_atom=res_of_atom(Mc), z=run_forward(m40, Xc, idsc, qc, Mc),
+         sizes=np.array([[300, int(b0[3].shape[1])], [40, int(b1[3].shape[1])]], dtype=np.int32))
+    # (c) coincident atoms: duplicate 3 atoms exactly -> D<1e-2 -> global-max fix-up (model_operations.py:12)
+    co = {k: v[:150].copy() for k, v in pdb_2cua.items()}
+    co["xyz"][10] = co["xyz"][11]
+    co["xyz"][77] = co["xyz"][20] + np.float32(1e-3)
+    c = encode(co, False)
+    Xc, idsc, qc, Mc = collate([list(c)])
+    # force a coincident atom INTO the neighbour list (extract_topology pushes them to the far end)
+    idsc = idsc.clone()
+    idsc[10, 5] = 12   # atom 11 (1-based 12) has the same coordinates as atom 10
+    idsc[20, 63] = 78  # atom 77 is 1e-3*sqrt(3) A from atom 20
+    save("edge_coincident", X=Xc.numpy(), ids_topk=idsc.numpy().astype(np.int32), q_idx=onehot_to_idx(qc, False),
+         res_of_atom=res_of_atom(Mc), z=run_forward(m40, Xc, idsc, qc, Mc))
+    # (d) residue with ONE atom + a big residue
+    sr = {k: v[:120].copy() for k, v in pdb_2cua.items()}
+    sr["resid"] = sr["resid"].copy()
+    sr["resid"][0] = 0               # own residue
+    sr["resid"][60:] = 1000          # one 60-atom residue
+    d = encode(sr, False)
+    Xc, idsc, qc, Mc = collate([list(d)])
+    save("edge_single_atom_residue", X=Xc.numpy(), ids_topk=idsc.numpy().astype(np.int32),
+         q_idx=onehot_to_idx(qc, False), res_of_atom=res_of_atom(Mc), z=run_forward(m40, Xc, idsc, qc, Mc))
+
+    # ------------------------------------------------------------------ i_v4_1 ARCHITECTURE (weights blob missing upstream)
+    cfg41, Model41, _ = import_reference("i_v4_1_2021-09-07_11-21")
+    assert len(cfg41["sum"]) == 32
+    m41 = Model41(cfg41).eval()
+    # stacked real weights (pesto_amd.weights.stack_layers): every i_v4_0 layer duplicated with its
+    # residual branch halved -> 32 layers with realistic activation magnitudes (|z| <~ 25)
+    from pesto_amd.weights import stack_layers
+    sd40 = {k: v.numpy() for k, v in m40.state_dict().items()}
+    sd41 = stack_layers(sd40, cfg41, residual_scale=0.5)
+    print("i_v4_1 stacked", m41.load_state_dict({k: pt.from_numpy(np.array(v)) for k, v in sd41.items()}))
+    for n, seed in ((512, 3), (3000, 1)):
+        X, ids, q, M = synth_inputs(n, seed)
+        Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+        z = run_forward(m41, Xc, idsc, qc, Mc)
+        print(f"  i_v4_1 stacked N={n}: |z|max={np.abs(z).max():.3f} finite={np.isfinite(z).all()}")
+        save(f"fwd_i_v4_1_stacked_synth{n}", z=z, seed=np.int64(seed), ids_topk=idsc.numpy().astype(np.int16 if n < 30000 else np.int32))
+    # and on real geometry
+    X, ids, q, M = encode(pdb_2cua, False)
+    Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+    save("fwd_i_v4_1_stacked_2CUA", z=run_forward(m41, Xc, idsc, qc, Mc))
+    X, ids, q, M = encode(pdb_2ayo, False)   # BASELINE config 1 geometry (inputs: fwd_i_v4_0_2AYO.npz)
+    Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+    save("fwd_i_v4_1_stacked_2AYO", z=run_forward(m41, Xc, idsc, qc, Mc))
+
+    # i_v3_0 (123 features) on synthetic N=512: three one-hots
+    cfg30, m30 = models["i_v3_0"]
+    import_reference("i_v3_0_2021-05-27_14-27")
+    X, ids, q, M = synth_inputs(512, 3, n0=123)
+    Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+    save("fwd_i_v3_0_synth512", z=run_forward(m30, Xc, idsc, qc, Mc), seed=np.int64(3))
+
+    # topology golden: reference extract_topology on a seeded cloud (package generator must match)
+    from pesto_amd.topology import synthetic_cloud
+    from src.data_encoding import extract_topology
+    X = pt.from_numpy(synthetic_cloud(300, 11))
+    save("topology_synth300", X=X.numpy(), ids_topk0=extract_topology(X, 64)[0].numpy().astype(np.int32))
+    X = pt.from_numpy(synthetic_cloud(50, 12))   # N < 64: knn = N, self sorted to the far end
+    save("topology_synth50", X=X.numpy(), ids_topk0=extract_topology(X, 64)[0].numpy().astype(np.int32))
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    main()
