@@ -1,0 +1,61 @@
+"""In-tree build of libpesto_hip.so for gfx950:  python -m pesto_amd.csrc.build [--force]
+
+hipcc cross-compiles without a GPU, so this also is the CPU-side "does it build" check (__graft_entry__.build).
+The .so is git-ignored but travels with the repo snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["pesto_schema.cpp", "pesto_kernels.hip", "pesto_layer_mfma.hip", "pesto_api.hip"]
+HEADERS = ["pesto_schema.h", "pesto_kernels.h", os.path.join("..", "..", "include", "pesto_hip.h")]
+OUT = os.path.join(HERE, "libpesto_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    jobs = []
+    for s in srcs:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [cc] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in srcs]
+    if force or jobs or _stale(OUT, objs):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

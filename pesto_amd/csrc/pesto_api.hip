@@ -1,0 +1,343 @@
+// pesto_api.hip - C ABI of libpesto_hip.so (declared in include/pesto_hip.h): model handle, grow-only device
+// workspace, the forward launch sequence on one HIP stream, per-stage entry points for the parity tests.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pesto_kernels.h"
+#include "pesto_schema.h"
+
+using namespace pesto;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(PESTO_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { if (hipFree(p) != hipSuccess) return -1; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) return -1;
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+}  // namespace
+
+struct pesto_model {
+    pesto_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;   // the model's own stream
+    DeviceImage img;                // host copy of tables (img.data released after upload)
+    float* W = nullptr;             // device weight image
+    // workspace (library owns weights + a grow-only workspace; no allocation once warm)
+    DevBuf ids_s, geo, q_a, p_a, q_b, p_b, pool_a, seg, z, flags;
+    DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
+    // state left by pesto_stage_unpack for pesto_stage_layer
+    int64_t stage_N = -1;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int n_layer_launches = 0;
+    bool have_timing = false;
+};
+
+namespace {
+
+size_t ws_bytes(int64_t N, int64_t R) {
+    const size_t N1 = (size_t)N + 1;
+    return N1 * KMAX * 4 + N1 * KMAX * 16 + 2 * (N1 * S * 4 + N1 * 96 * 4) + (size_t)N * 8 * 4 + (size_t)R * 8 + (size_t)R * 32 * 4 + 64;
+}
+
+int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
+    const size_t N1 = (size_t)N + 1;
+    int rc = 0;
+    rc |= m->ids_s.ensure(N1 * KMAX * sizeof(int));
+    rc |= m->geo.ensure(N1 * KMAX * sizeof(float4));
+    rc |= m->q_a.ensure(N1 * S * sizeof(float));
+    rc |= m->p_a.ensure(N1 * 96 * sizeof(float));
+    rc |= m->q_b.ensure(N1 * S * sizeof(float));
+    rc |= m->p_b.ensure(N1 * 96 * sizeof(float));
+    rc |= m->pool_a.ensure((size_t)N * 8 * sizeof(float));
+    rc |= m->seg.ensure((size_t)(R > 0 ? R : 1) * 2 * sizeof(int));
+    rc |= m->z.ensure((size_t)(R > 0 ? R : 1) * 32 * sizeof(float));
+    rc |= m->flags.ensure(64);
+    return rc ? fail(PESTO_ERR_NOMEM, "device workspace allocation failed for N=%lld R=%lld", (long long)N, (long long)R) : 0;
+}
+
+// flags buffer layout: [0] dmax bits (unsigned), [1] error flag (int)
+unsigned* dmax_ptr(pesto_model* m) { return m->flags.as<unsigned>(); }
+int* err_ptr(pesto_model* m) { return m->flags.as<int>() + 1; }
+
+int check_device_flag(pesto_model* m, hipStream_t st) {
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, err_ptr(m), sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (flag & 1) return fail(PESTO_ERR_INVALID, "ids_topk contains an index outside [0, N]");
+    if (flag & 2) return fail(PESTO_ERR_INVALID, "res_of_atom contains an index outside [0, R)");
+    return 0;
+}
+
+// the launch sequence of Model.forward (model/model.py:32-52) on stream st; all pointers are device pointers
+int run_forward(pesto_model* m, hipStream_t st, int64_t N, int64_t R, int k, const float* X, const void* ids, int ids_kind,
+                const float* q0, const int* roa, float* z_out, float* qr_out, float* pr_out) {
+    const int N1 = (int)N + 1;
+    float* q[2] = {m->q_a.as<float>(), m->q_b.as<float>()};
+    float* p[2] = {m->p_a.as<float>(), m->p_b.as<float>()};
+    HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(q[0], 0, S * sizeof(float), st));                       // sink row of q (model_operations.py:17)
+    HIP_TRY(hipMemsetAsync(p[0], 0, (size_t)N1 * 96 * sizeof(float), st));         // p0 = zeros (model.py:37)
+    if (m->timing) HIP_TRY(hipEventRecord(m->ev[0], st));
+    launch_embed(st, m->W, m->img.model.em, (int)N, m->cfg.n0, q0, q[0]);
+    launch_unpack(st, (int)N, k, X, ids, ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(), dmax_ptr(m), err_ptr(m));
+    if (m->timing) HIP_TRY(hipEventRecord(m->ev[1], st));
+    int cur = 0;
+    for (int l = 0; l < m->cfg.n_layers; ++l) {
+        launch_layer_v1(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), q[cur], p[cur], q[cur ^ 1], p[cur ^ 1]);
+        cur ^= 1;
+    }
+    if (m->timing) { HIP_TRY(hipEventRecord(m->ev[2], st)); m->n_layer_launches = m->cfg.n_layers; m->have_timing = true; }
+    launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)N, (int)R, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
+                m->seg.as<int>(), m->seg.as<int>() + R, err_ptr(m), qr_out, pr_out, z_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int check_model(const pesto_model* m) { return m ? 0 : fail(PESTO_ERR_INVALID, "null model handle"); }
+
+}  // namespace
+
+extern "C" {
+
+const char* pesto_last_error(void) { return g_err.c_str(); }
+
+int pesto_blob_size(const pesto_config* cfg, int64_t* n_floats) {
+    if (!config_ok(cfg) || !n_floats) return fail(PESTO_ERR_INVALID, "invalid pesto_config");
+    *n_floats = host_schema(*cfg).total;
+    return 0;
+}
+
+int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weights, int device, pesto_model** out) {
+    if (!out) return fail(PESTO_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!config_ok(cfg)) return fail(PESTO_ERR_INVALID, "invalid pesto_config (nn must be 8/16/32/64, depths 1 or 3, n_out <= 32)");
+    const int64_t need = host_schema(*cfg).total;
+    if (!weights || n_weights != need)
+        return fail(PESTO_ERR_INVALID, "weight blob has %lld floats, config needs %lld", (long long)n_weights, (long long)need);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(PESTO_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    pesto_model* m = new pesto_model();
+    m->cfg = *cfg;
+    m->device = device;
+    m->img = build_device_image(*cfg, weights);
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->W, m->img.data.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(m->W, m->img.data.data(), m->img.data.size() * sizeof(float), hipMemcpyHostToDevice);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&m->ev[i]);
+    if (e != hipSuccess) {
+        pesto_destroy(m);
+        return fail(PESTO_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
+    }
+    std::vector<float>().swap(m->img.data);
+    *out = m;
+    return 0;
+}
+
+int pesto_destroy(pesto_model* m) {
+    if (!m) return 0;
+    hipSetDevice(m->device);
+    if (m->stream) { hipStreamSynchronize(m->stream); hipStreamDestroy(m->stream); }
+    for (auto& e : m->ev) if (e) hipEventDestroy(e);
+    if (m->W) hipFree(m->W);
+    for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa})
+        b->release();
+    delete m;
+    return 0;
+}
+
+int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* bytes) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (N < 1 || R < 1 || !bytes) return fail(PESTO_ERR_INVALID, "bad arguments");
+    *bytes = (int64_t)ws_bytes(N, R);
+    return 0;
+}
+
+int pesto_synchronize(pesto_model* m) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int pesto_set_timing(pesto_model* m, int32_t enabled) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    m->timing = enabled != 0;
+    m->have_timing = false;
+    return 0;
+}
+
+int pesto_get_timing(pesto_model* m, double* layers_ms, double* total_ms, int32_t* n_layer_launches) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (!m->have_timing) return fail(PESTO_ERR_STATE, "no timed forward has run (pesto_set_timing + pesto_forward)");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipEventSynchronize(m->ev[2]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, m->ev[1], m->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&b, m->ev[0], m->ev[2]));
+    if (layers_ms) *layers_ms = a;
+    if (total_ms) *total_ms = b;
+    if (n_layer_launches) *n_layer_launches = m->n_layer_launches;
+    return 0;
+}
+
+int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k, const float* X, const void* ids_topk, int32_t ids_kind,
+                  const float* q0, const int32_t* res_of_atom, float* z_out, int32_t ptr_kind, void* stream) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || R > N) return fail(PESTO_ERR_INVALID, "bad sizes N=%lld R=%lld", (long long)N, (long long)R);
+    if (k < 1 || k > KMAX) return fail(PESTO_ERR_INVALID, "k=%d must be in 1..%d", k, KMAX);
+    for (int l = 0; l < m->cfg.n_layers; ++l)
+        if (m->cfg.nn[l] > KMAX) return fail(PESTO_ERR_INVALID, "layer nn exceeds %d", KMAX);
+    if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
+    if (!X || !ids_topk || !q0 || !res_of_atom || !z_out) return fail(PESTO_ERR_INVALID, "null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    if (int rc = ensure_workspace(m, N, R)) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
+    if (ptr_kind == PESTO_PTR_DEVICE)
+        return run_forward(m, st, N, R, k, X, ids_topk, ids_kind, q0, res_of_atom, z_out, nullptr, nullptr);
+    if (ptr_kind != PESTO_PTR_HOST) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
+    if (m->in_X.ensure((size_t)N * 3 * 4) || m->in_ids.ensure((size_t)N * k * id_sz) || m->in_q0.ensure((size_t)N * m->cfg.n0 * 4) ||
+        m->in_roa.ensure((size_t)N * 4))
+        return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    HIP_TRY(hipMemcpyAsync(m->in_X.p, X, (size_t)N * 3 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->in_ids.p, ids_topk, (size_t)N * k * id_sz, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->in_q0.p, q0, (size_t)N * m->cfg.n0 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->in_roa.p, res_of_atom, (size_t)N * 4, hipMemcpyHostToDevice, st));
+    if (int rc = run_forward(m, st, N, R, k, m->in_X.as<float>(), m->in_ids.p, ids_kind, m->in_q0.as<float>(), m->in_roa.as<int>(),
+                             m->z.as<float>(), nullptr, nullptr))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(z_out, m->z.p, (size_t)R * m->cfg.n_out * 4, hipMemcpyDeviceToHost, st));
+    return check_device_flag(m, st);   // synchronises
+}
+
+// ------------------------------------------------------------------ per-stage entry points (host pointers)
+int pesto_stage_embed(pesto_model* m, int64_t N, const float* q0, float* q_out) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (N < 1 || !q0 || !q_out) return fail(PESTO_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(m->device));
+    if (int rc = ensure_workspace(m, N, 1)) return rc;
+    if (m->in_q0.ensure((size_t)N * m->cfg.n0 * 4)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    hipStream_t st = m->stream;
+    HIP_TRY(hipMemcpyAsync(m->in_q0.p, q0, (size_t)N * m->cfg.n0 * 4, hipMemcpyHostToDevice, st));
+    launch_embed(st, m->W, m->img.model.em, (int)N, m->cfg.n0, m->in_q0.as<float>(), m->q_a.as<float>());
+    HIP_TRY(hipMemcpyAsync(q_out, m->q_a.as<float>() + S, (size_t)N * S * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    m->stage_N = -1;
+    return 0;
+}
+
+int pesto_stage_unpack(pesto_model* m, int64_t N, int32_t k, const float* X, const void* ids_topk, int32_t ids_kind,
+                       float* D_out, float* R_out) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (N < 1 || k < 1 || k > KMAX || !X || !ids_topk) return fail(PESTO_ERR_INVALID, "bad arguments");
+    if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
+    HIP_TRY(hipSetDevice(m->device));
+    if (int rc = ensure_workspace(m, N, 1)) return rc;
+    const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
+    if (m->in_X.ensure((size_t)N * 3 * 4) || m->in_ids.ensure((size_t)N * k * id_sz)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    hipStream_t st = m->stream;
+    HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
+    HIP_TRY(hipMemcpyAsync(m->in_X.p, X, (size_t)N * 3 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->in_ids.p, ids_topk, (size_t)N * k * id_sz, hipMemcpyHostToDevice, st));
+    launch_unpack(st, (int)N, k, m->in_X.as<float>(), m->in_ids.p, ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(), dmax_ptr(m), err_ptr(m));
+    if (int rc = check_device_flag(m, st)) return rc;
+    m->stage_N = N;
+    if (D_out || R_out) {
+        std::vector<float4> g((size_t)(N + 1) * KMAX);
+        HIP_TRY(hipMemcpy(g.data(), m->geo.p, g.size() * sizeof(float4), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i <= N; ++i)
+            for (int c = 0; c < k; ++c) {
+                const float4 v = g[(size_t)i * KMAX + c];
+                if (D_out) D_out[i * k + c] = v.w;
+                if (R_out) { R_out[(i * k + c) * 3] = v.x; R_out[(i * k + c) * 3 + 1] = v.y; R_out[(i * k + c) * 3 + 2] = v.z; }
+            }
+    }
+    return 0;
+}
+
+int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (m->stage_N < 1) return fail(PESTO_ERR_STATE, "pesto_stage_unpack must run first");
+    if (layer < 0 || layer >= m->cfg.n_layers || !q_io || !p_io) return fail(PESTO_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t N1 = (size_t)m->stage_N + 1;
+    hipStream_t st = m->stream;
+    HIP_TRY(hipMemcpyAsync(m->q_a.p, q_io, N1 * S * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->p_a.p, p_io, N1 * 96 * 4, hipMemcpyHostToDevice, st));
+    launch_layer_v1(st, m->W, m->img.layers[layer], (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->q_a.as<float>(), m->p_a.as<float>(),
+                    m->q_b.as<float>(), m->p_b.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(q_io, m->q_b.p, N1 * S * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(p_io, m->p_b.p, N1 * 96 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int pesto_stage_pool(pesto_model* m, int64_t N, int64_t R, const float* q, const float* p, const int32_t* res_of_atom,
+                     float* qr_out, float* pr_out, float* z_out) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (N < 1 || R < 1 || !q || !p || !res_of_atom || !z_out) return fail(PESTO_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(m->device));
+    if (int rc = ensure_workspace(m, N, R)) return rc;
+    if (m->in_roa.ensure((size_t)N * 4)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    DevBuf qr, pr;
+    if (qr.ensure((size_t)R * S * 4) || pr.ensure((size_t)R * 96 * 4)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    hipStream_t st = m->stream;
+    int rc = 0;
+    do {
+        if (hipMemsetAsync(m->flags.p, 0, 8, st) != hipSuccess) { rc = fail(PESTO_ERR_HIP, "memset failed"); break; }
+        hipMemcpyAsync(m->q_a.as<float>() + S, q, (size_t)N * S * 4, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(m->p_a.as<float>() + 96, p, (size_t)N * 96 * 4, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(m->in_roa.p, res_of_atom, (size_t)N * 4, hipMemcpyHostToDevice, st);
+        launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)N, (int)R, m->q_a.as<float>() + S, m->p_a.as<float>() + 96, m->in_roa.as<int>(),
+                    m->pool_a.as<float>(), m->seg.as<int>(), m->seg.as<int>() + R, err_ptr(m), qr.as<float>(), pr.as<float>(), m->z.as<float>());
+        if (qr_out) hipMemcpyAsync(qr_out, qr.p, (size_t)R * S * 4, hipMemcpyDeviceToHost, st);
+        if (pr_out) hipMemcpyAsync(pr_out, pr.p, (size_t)R * 96 * 4, hipMemcpyDeviceToHost, st);
+        hipMemcpyAsync(z_out, m->z.p, (size_t)R * m->cfg.n_out * 4, hipMemcpyDeviceToHost, st);
+        rc = check_device_flag(m, st);
+    } while (0);
+    qr.release(); pr.release();
+    m->stage_N = -1;
+    return rc;
+}
+
+}  // extern "C"

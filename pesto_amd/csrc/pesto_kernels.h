@@ -1,0 +1,17 @@
+// pesto_kernels.h - launchers of the gfx950 kernels (definitions in pesto_kernels.hip / pesto_layer_mfma.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pesto_schema.h"
+
+namespace pesto {
+
+void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int n0, const float* q0, float* q_state);
+void launch_unpack(hipStream_t st, int N, int k, const float* X, const void* ids, int ids_kind, int* ids_s, float4* geo,
+                   unsigned* dmax_bits, int* err_flag);
+void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
+                     const float* q_in, const float* p_in, float* q_out, float* p_out);
+void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,
+                 const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out);
+
+}  // namespace pesto

@@ -1,0 +1,501 @@
+// pesto_kernels.hip - gfx950 kernels of the PeSTo forward pass: embedding, geometry unpack, the v1
+// state-update layer (LDS-tiled fp32 VALU; the MFMA layer lives in pesto_layer_mfma.hip), residue pool + decoder.
+//
+// Math restated from the reference (file:line relative to /root/reference):
+//   embedding              model/model.py:34
+//   geometry + sink        src/model_operations.py:6-22
+//   state-update layer     src/model_operations.py:87-154, :225-242
+//   residue pool + decoder src/model_operations.py:197-213, model/model.py:46-50
+#include <hip/hip_runtime.h>
+
+#include "pesto_kernels.h"
+
+namespace pesto {
+
+__device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expf(x) - 1.0f; }
+
+// One output column `s` of y = x Wt + b for a group of 32 lanes; x lives in LDS (read as broadcast),
+// Wt[in][out] in global memory (lanes read consecutive floats).
+__device__ __forceinline__ float g32_linear(const float* __restrict__ W, const LinearW l, const float* x, int s) {
+    if (s >= l.n_out) return 0.0f;
+    float acc = l.b >= 0 ? W[l.b + s] : 0.0f;
+    const float* w = W + l.w + s;
+    for (int k = 0; k < l.n_in; ++k) acc += x[k] * w[k * l.n_out];
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------ embedding
+// q[i+1][:] = em(q0[i][:]) ; 8 atoms per 256-thread block, 32 lanes per atom.  model/model.py:34
+__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW em, int N, int n0,
+                                               const float* __restrict__ q0, float* __restrict__ q_state) {
+    __shared__ float xs[8][512];
+    __shared__ float hs[8][64];
+    const int g = threadIdx.x >> 5, s = threadIdx.x & 31;
+    const int i = blockIdx.x * 8 + g;
+    const int ic = i < N ? i : N - 1;
+    for (int k = s; k < n0; k += 32) xs[g][k] = q0[(size_t)ic * n0 + k];
+    __syncthreads();
+    float v = g32_linear(W, em.l[0], xs[g], s);
+    if (em.depth == 3) {
+        hs[g][s] = elu(v);
+        __syncthreads();
+        v = g32_linear(W, em.l[1], hs[g], s);
+        hs[g][32 + s] = elu(v);
+        __syncthreads();
+        v = g32_linear(W, em.l[2], hs[g] + 32, s);
+    }
+    if (i < N) q_state[(size_t)(i + 1) * S + s] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ geometry
+// pass 1: R = X[ids-1] - X[i] (ids-1 = -1 wraps to the last atom), D = |R|, block max -> atomic max of the
+// float bit pattern (D >= 0). Output rows are shifted by the sink row.   src/model_operations.py:8-10
+template <typename IdT>
+__global__ __launch_bounds__(256) void k_unpack1(int N, int k, const float* __restrict__ X, const IdT* __restrict__ ids,
+                                                 int* __restrict__ ids_s, float4* __restrict__ geo,
+                                                 unsigned* __restrict__ dmax_bits, int* __restrict__ err_flag) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over N * 64 slots
+    float d = 0.0f;
+    if (e < (int64_t)N * KMAX) {
+        const int i = (int)(e >> 6), c = (int)(e & 63);
+        long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
+        if (id < 0 || id > N) { atomicOr(err_flag, 1); id = 0; }
+        long long j = id - 1;
+        if (j < 0) j += N;
+        const float rx = X[3 * j] - X[3 * i], ry = X[3 * j + 1] - X[3 * i + 1], rz = X[3 * j + 2] - X[3 * i + 2];
+        d = sqrtf(rx * rx + ry * ry + rz * rz);
+        ids_s[(size_t)(i + 1) * KMAX + c] = (int)id;
+        geo[(size_t)(i + 1) * KMAX + c] = make_float4(rx, ry, rz, d);
+    }
+    // wave max, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) d = fmaxf(d, __shfl_xor(d, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(dmax_bits, __float_as_uint(d));
+}
+
+// pass 2: D += max(D) * (D < 1e-2);  R /= D.  Also writes the sink row 0.   src/model_operations.py:12-20
+__global__ __launch_bounds__(256) void k_unpack2(int N, int* __restrict__ ids_s, float4* __restrict__ geo,
+                                                 const unsigned* __restrict__ dmax_bits) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over (N+1) * 64 slots
+    if (e >= (int64_t)(N + 1) * KMAX) return;
+    if (e < KMAX) { ids_s[e] = 0; geo[e] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const float dmax = __uint_as_float(*dmax_bits);
+    float4 g = geo[e];
+    const float d = g.w + dmax * (g.w < 1e-2f ? 1.0f : 0.0f);
+    geo[e] = make_float4(g.x / d, g.y / d, g.z / d, d);
+}
+
+// ------------------------------------------------------------------------------------------------ layer v1
+// One workgroup = 64 edge rows = A = 64/NN centre atoms. fp32 VALU, operands staged k-major in LDS so every
+// thread owns one output column and 32 rows (broadcast ds_read_b128 of the rows, coalesced weight reads).
+// The centre block X_n(i) of the 193-wide edge input is folded into a per-centre partial sum (exact algebra).
+constexpr int LD = 68;   // row stride of the k-major LDS tiles: 64 rows + 4 pad (keeps b128 alignment)
+
+struct LayerSmem {
+    float xe[129 * LD];    // varying part of X_e, k-major: 0 d | 1..32 q_j | 33..64 |p_j| | 65..96 p_i.r | 97..128 p_j.r ; reused as h2[128][LD]
+    float h1[128 * LD];    // layer-1 activations, k-major; reused as kv[76][LD] (0-2 Kq, 3-11 Kp, 12-43 V0, 44-75 V1)
+    float xn[8 * 64];      // centre node features [q_i | |p_i|]
+    float pis[8 * 96];     // centre p_i
+    float cpart[8 * 128];  // b1 + W1[:, 1:65] X_n(i)
+    float4 geo[64];        // (r_hat, d) per row
+    int nb[64];            // neighbour id per row
+    float tmp[8 * 64];
+    float Q[8 * 16];
+    float lg[8 * 64];      // [h][part][row] logits -> attention weights
+    float ex[8 * 64];
+    float zs[8 * 256];     // [centre][Zq | Zp_x | Zp_y | Zp_z][h*32+s]
+};
+
+template <int NN>
+__global__ __launch_bounds__(256) void k_layer_v1(const float* __restrict__ W, LayerW lw, int N1,
+                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
+                                                  const float* __restrict__ q_in, const float* __restrict__ p_in,
+                                                  float* __restrict__ q_out, float* __restrict__ p_out) {
+    constexpr int A = 64 / NN;
+    __shared__ LayerSmem sm;
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * A;
+    const float sdk = sqrtf((float)NK);
+
+    // ---- phase 0: rows' neighbour ids + geometry, centre states
+    if (t < 64) {
+        const int a = t / NN, c = t % NN, i = c0 + a;
+        const bool valid = i < N1;
+        sm.nb[t] = valid ? ids_s[(size_t)i * KMAX + c] : 0;
+        sm.geo[t] = valid ? geo[(size_t)i * KMAX + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    {
+        const int a = t >> 5, s = t & 31;
+        if (a < A) {
+            const int i = min(c0 + a, N1 - 1);
+            const float qv = q_in[(size_t)i * S + s];
+            const float p0 = p_in[(size_t)i * 96 + s], p1 = p_in[(size_t)i * 96 + 32 + s], p2 = p_in[(size_t)i * 96 + 64 + s];
+            sm.xn[a * 64 + s] = qv;
+            sm.xn[a * 64 + 32 + s] = sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
+            sm.pis[a * 96 + s] = p0; sm.pis[a * 96 + 32 + s] = p1; sm.pis[a * 96 + 64 + s] = p2;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: gather neighbour states, build the varying edge features (k-major)
+    {
+        const int s = t & 31, rg = t >> 5;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = rg + 8 * it, a = r / NN;
+            const int j = sm.nb[r];
+            const float4 g = sm.geo[r];
+            const float qj = q_in[(size_t)j * S + s];
+            const float pj0 = p_in[(size_t)j * 96 + s], pj1 = p_in[(size_t)j * 96 + 32 + s], pj2 = p_in[(size_t)j * 96 + 64 + s];
+            sm.xe[(1 + s) * LD + r] = qj;
+            sm.xe[(33 + s) * LD + r] = sqrtf(pj0 * pj0 + pj1 * pj1 + pj2 * pj2);
+            sm.xe[(65 + s) * LD + r] = sm.pis[a * 96 + s] * g.x + sm.pis[a * 96 + 32 + s] * g.y + sm.pis[a * 96 + 64 + s] * g.z;
+            sm.xe[(97 + s) * LD + r] = pj0 * g.x + pj1 * g.y + pj2 * g.z;
+            if (s == 0) sm.xe[r] = g.w;
+        }
+    }
+    // ---- phase 2: per-centre part of edge layer 1, and the node query MLP (first layer)
+    const int o = t & 127, rh = t >> 7;
+    for (int a = rh; a < A; a += 2) {
+        float acc = W[lw.b1 + o];
+        for (int k = 0; k < 64; ++k) acc += sm.xn[a * 64 + k] * W[lw.w1 + (1 + k) * 128 + o];
+        sm.cpart[a * 128 + o] = acc;
+    }
+    {
+        const int a = t >> 5, s = t & 31;
+        if (a < A) sm.tmp[a * 64 + s] = elu(g32_linear(W, lw.nqm.l[0], sm.xn + a * 64, s));
+    }
+    __syncthreads();
+    {
+        const int a = t >> 5, s = t & 31;
+        if (a < A) sm.tmp[a * 64 + 32 + s] = elu(g32_linear(W, lw.nqm.l[1], sm.tmp + a * 64, s));
+    }
+    __syncthreads();
+    {
+        const int a = t >> 5, s = t & 31;
+        if (a < A && s < 12) sm.Q[a * 16 + s] = g32_linear(W, lw.nqm.l[2], sm.tmp + a * 64 + 32, s);
+    }
+
+    // ---- phase 3: edge layer 1 -> h1 (ELU), column o, rows rh*32..+31
+    float acc[32];
+    {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) acc[m] = sm.cpart[((rh * 32 + m) / NN) * 128 + o];
+        for (int k = 0; k < 129; ++k) {
+            const float w = W[lw.w1 + (k == 0 ? 0 : 64 + k) * 128 + o];
+            const float4* xr = reinterpret_cast<const float4*>(sm.xe + k * LD + rh * 32);
+#pragma unroll
+            for (int m4 = 0; m4 < 8; ++m4) {
+                const float4 v = xr[m4];
+                acc[4 * m4 + 0] += v.x * w; acc[4 * m4 + 1] += v.y * w; acc[4 * m4 + 2] += v.z * w; acc[4 * m4 + 3] += v.w * w;
+            }
+        }
+        float4* hw = reinterpret_cast<float4*>(sm.h1 + o * LD + rh * 32);
+#pragma unroll
+        for (int m4 = 0; m4 < 8; ++m4)
+            hw[m4] = make_float4(elu(acc[4 * m4]), elu(acc[4 * m4 + 1]), elu(acc[4 * m4 + 2]), elu(acc[4 * m4 + 3]));
+    }
+    __syncthreads();
+
+    // ---- phase 4: edge layer 2 (block diagonal: eq 32->32, ep 32->32, ev 64->64) -> h2 (in the xe region)
+    {
+        int kb, kn, ldw, oc; const float* wp;
+        if (o < 32) { kb = 0; kn = 32; ldw = 32; oc = o; wp = W + lw.w2eq; }
+        else if (o < 64) { kb = 32; kn = 32; ldw = 32; oc = o - 32; wp = W + lw.w2ep; }
+        else { kb = 64; kn = 64; ldw = 64; oc = o - 64; wp = W + lw.w2ev; }
+        const float b = W[lw.b2 + o];
+#pragma unroll
+        for (int m = 0; m < 32; ++m) acc[m] = b;
+        for (int k = 0; k < kn; ++k) {
+            const float w = wp[k * ldw + oc];
+            const float4* xr = reinterpret_cast<const float4*>(sm.h1 + (kb + k) * LD + rh * 32);
+#pragma unroll
+            for (int m4 = 0; m4 < 8; ++m4) {
+                const float4 v = xr[m4];
+                acc[4 * m4 + 0] += v.x * w; acc[4 * m4 + 1] += v.y * w; acc[4 * m4 + 2] += v.z * w; acc[4 * m4 + 3] += v.w * w;
+            }
+        }
+        float4* hw = reinterpret_cast<float4*>(sm.xe + o * LD + rh * 32);
+#pragma unroll
+        for (int m4 = 0; m4 < 8; ++m4)
+            hw[m4] = make_float4(elu(acc[4 * m4]), elu(acc[4 * m4 + 1]), elu(acc[4 * m4 + 2]), elu(acc[4 * m4 + 3]));
+    }
+    __syncthreads();
+
+    // ---- phase 5: edge layer 3 -> kv (in the h1 region): rows 0-2 Kq, 3-11 Kp (raw, chunk t = rows 3+3t..), 12-75 V
+    if (o < 76) {
+        int kb, kn, ldw, oc; const float* wp;
+        if (o < 3) { kb = 0; kn = 32; ldw = 3; oc = o; wp = W + lw.w3eq; }
+        else if (o < 12) { kb = 32; kn = 32; ldw = 9; oc = o - 3; wp = W + lw.w3ep; }
+        else { kb = 64; kn = 64; ldw = 64; oc = o - 12; wp = W + lw.w3ev; }
+        const float b = W[lw.b3 + o];
+#pragma unroll
+        for (int m = 0; m < 32; ++m) acc[m] = b;
+        for (int k = 0; k < kn; ++k) {
+            const float w = wp[k * ldw + oc];
+            const float4* xr = reinterpret_cast<const float4*>(sm.xe + (kb + k) * LD + rh * 32);
+#pragma unroll
+            for (int m4 = 0; m4 < 8; ++m4) {
+                const float4 v = xr[m4];
+                acc[4 * m4 + 0] += v.x * w; acc[4 * m4 + 1] += v.y * w; acc[4 * m4 + 2] += v.z * w; acc[4 * m4 + 3] += v.w * w;
+            }
+        }
+        float4* hw = reinterpret_cast<float4*>(sm.h1 + o * LD + rh * 32);
+#pragma unroll
+        for (int m4 = 0; m4 < 8; ++m4) hw[m4] = make_float4(acc[4 * m4], acc[4 * m4 + 1], acc[4 * m4 + 2], acc[4 * m4 + 3]);
+    }
+    __syncthreads();
+    const float* kv = sm.h1;
+
+    // ---- phase 7: attention logits and softmax. part 0: scalar keys over NN slots; parts 1..3: the three
+    // vector-key chunks, softmaxed TOGETHER over 3*NN slots (chunk-major, model_operations.py:125,140)
+    {
+        const int r = t & 63, part = t >> 6, a = r / NN, g0 = a * NN;
+        const int kr = part == 0 ? 0 : 3 + (part - 1) * 3;
+        float l[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float* Qv = sm.Q + a * 16 + (part ? 6 : 0) + h * 3;
+            l[h] = (Qv[0] * kv[(kr + 0) * LD + r] + Qv[1] * kv[(kr + 1) * LD + r] + Qv[2] * kv[(kr + 2) * LD + r]) / sdk;
+            sm.lg[(h * 4 + part) * 64 + r] = l[h];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float mx = -INFINITY;
+            if (part == 0) {
+                for (int c = 0; c < NN; ++c) mx = fmaxf(mx, sm.lg[(h * 4) * 64 + g0 + c]);
+            } else {
+                for (int pp = 1; pp < 4; ++pp)
+                    for (int c = 0; c < NN; ++c) mx = fmaxf(mx, sm.lg[(h * 4 + pp) * 64 + g0 + c]);
+            }
+            l[h] = expf(l[h] - mx);
+            sm.ex[(h * 4 + part) * 64 + r] = l[h];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float sum = 0.0f;
+            if (part == 0) {
+                for (int c = 0; c < NN; ++c) sum += sm.ex[(h * 4) * 64 + g0 + c];
+            } else {
+                for (int pp = 1; pp < 4; ++pp)
+                    for (int c = 0; c < NN; ++c) sum += sm.ex[(h * 4 + pp) * 64 + g0 + c];
+            }
+            sm.lg[(h * 4 + part) * 64 + r] = l[h] / sum;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 8: attention-weighted sums Zq [h*32+s], Zp[x][h*32+s]   (model_operations.py:131-144)
+    {
+        const int s = t & 31, h = (t >> 5) & 1, xq = t >> 6;
+        for (int a = 0; a < A; ++a) {
+            const int g0 = a * NN;
+            float z = 0.0f;
+            if (xq == 0) {
+                for (int c = 0; c < NN; ++c) z += sm.lg[(h * 4) * 64 + g0 + c] * kv[(12 + s) * LD + g0 + c];
+            } else {
+                const int x = xq - 1;
+                float wsum = 0.0f, z3 = 0.0f;
+                for (int c = 0; c < NN; ++c) {
+                    const int r = g0 + c;
+                    const float4 g = sm.geo[r];
+                    const float gx = x == 0 ? g.x : (x == 1 ? g.y : g.z);
+                    z += sm.lg[(h * 4 + 1) * 64 + r] * (kv[(44 + s) * LD + r] * gx);
+                    wsum += sm.lg[(h * 4 + 2) * 64 + r];
+                    z3 += sm.lg[(h * 4 + 3) * 64 + r] * p_in[(size_t)sm.nb[r] * 96 + x * 32 + s];
+                }
+                z += wsum * sm.pis[a * 96 + x * 32 + s];
+                z += z3;
+            }
+            sm.zs[a * 256 + xq * 64 + h * 32 + s] = z;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 9: output MLPs + residual, sink row reset   (model_operations.py:147-152, :239-240)
+    {
+        const int a = t >> 5, s = t & 31;
+        const bool act = a < A;
+        if (act) sm.tmp[a * 64 + s] = elu(g32_linear(W, lw.qpm.l[0], sm.zs + a * 256, s));
+        __syncthreads();
+        if (act) sm.tmp[a * 64 + 32 + s] = elu(g32_linear(W, lw.qpm.l[1], sm.tmp + a * 64, s));
+        __syncthreads();
+        if (act) {
+            const int i = c0 + a;
+            if (i < N1) {
+                const float qh = g32_linear(W, lw.qpm.l[2], sm.tmp + a * 64 + 32, s);
+                const bool sink = i == 0;
+                q_out[(size_t)i * S + s] = sink ? 0.0f : sm.xn[a * 64 + s] + qh;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const float ph = g32_linear(W, lw.ppm, sm.zs + a * 256 + (1 + x) * 64, s);
+                    p_out[(size_t)i * 96 + x * 32 + s] = sink ? 0.0f : sm.pis[a * 96 + x * 32 + s] + ph;
+                }
+            }
+        }
+    }
+}
+
+void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
+                     const float* q_in, const float* p_in, float* q_out, float* p_out) {
+    const int A = 64 / lw.nn;
+    const dim3 grid((N1 + A - 1) / A), block(256);
+    switch (lw.nn) {
+        case 8: hipLaunchKernelGGL(k_layer_v1<8>, grid, block, 0, st, W, lw, N1, ids_s, geo, q_in, p_in, q_out, p_out); break;
+        case 16: hipLaunchKernelGGL(k_layer_v1<16>, grid, block, 0, st, W, lw, N1, ids_s, geo, q_in, p_in, q_out, p_out); break;
+        case 32: hipLaunchKernelGGL(k_layer_v1<32>, grid, block, 0, st, W, lw, N1, ids_s, geo, q_in, p_in, q_out, p_out); break;
+        default: hipLaunchKernelGGL(k_layer_v1<64>, grid, block, 0, st, W, lw, N1, ids_s, geo, q_in, p_in, q_out, p_out); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ residue pool
+// segment bounds: lo[r] = min atom index with res_of_atom == r, hi[r] = max + 1 (integer atomics: deterministic)
+__global__ void k_seg_init(int R, int* __restrict__ lo, int* __restrict__ hi) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) { lo[r] = 0x7fffffff; hi[r] = 0; }
+}
+__global__ void k_seg_bounds(int N, int R, const int* __restrict__ roa, int* __restrict__ lo, int* __restrict__ hi,
+                             int* __restrict__ err_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int r = roa[i];
+    if (r < 0 || r >= R) { atomicOr(err_flag, 2); return; }
+    atomicMin(&lo[r], i);
+    atomicMax(&hi[r], i + 1);
+}
+
+// per-atom pool logits a[i][0..7] = sam([q_i | |p_i|]) + F_member   (model_operations.py:199-205)
+__global__ __launch_bounds__(256) void k_pool_logits(const float* __restrict__ W, MlpW sam, int N,
+                                                     const float* __restrict__ q, const float* __restrict__ p,
+                                                     float* __restrict__ a_out) {
+    __shared__ float zin[8][64];
+    __shared__ float hs[8][64];
+    const int g = threadIdx.x >> 5, s = threadIdx.x & 31;
+    const int i = blockIdx.x * 8 + g;
+    const int ic = i < N ? i : N - 1;
+    const float p0 = p[(size_t)ic * 96 + s], p1 = p[(size_t)ic * 96 + 32 + s], p2 = p[(size_t)ic * 96 + 64 + s];
+    zin[g][s] = q[(size_t)ic * S + s];
+    zin[g][32 + s] = sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
+    __syncthreads();
+    hs[g][s] = elu(g32_linear(W, sam.l[0], zin[g], s));
+    __syncthreads();
+    hs[g][32 + s] = elu(g32_linear(W, sam.l[1], hs[g], s));
+    __syncthreads();
+    const float f_member = (1.0f - 1.0f + 1e-6f) / (1.0f - 1e-6f);
+    if (i < N && s < 2 * PH) a_out[(size_t)i * 8 + s] = g32_linear(W, sam.l[2], hs[g] + 32, s) + f_member;
+}
+
+// one wave per residue: segmented softmax over its atoms for the 8 channels (2h = scalar head h, 2h+1 = vector
+// head h), weighted sums flattened s*4+h, zdm / zdm_vec, norm, decoder.   model_operations.py:205-211, model.py:49-50
+__global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W, ModelW mw, int n_out, int R,
+                                                    const float* __restrict__ q, const float* __restrict__ p,
+                                                    const float* __restrict__ a, const int* __restrict__ roa,
+                                                    const int* __restrict__ lo, const int* __restrict__ hi,
+                                                    float* __restrict__ qr_out, float* __restrict__ pr_out,
+                                                    float* __restrict__ z_out) {
+    __shared__ float qh[128];
+    __shared__ float ph[3][128];
+    __shared__ float hs[64];
+    __shared__ float zr[64];
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x, s = lane & 31, hf = lane >> 5;
+    const int i0 = lo[r], i1 = hi[r];
+    if (i0 >= i1) {   // empty residue: the reference degenerates to a whole-batch softmax; flagged with NaN here
+        if (lane < n_out) z_out[(size_t)r * n_out + lane] = __uint_as_float(0x7fc00000u);
+        return;
+    }
+    float mx[4], den[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { mx[c] = -INFINITY; den[c] = 0.0f; }
+    for (int i = i0; i < i1; ++i)
+        if (roa[i] == r) {
+            const float4 v = *reinterpret_cast<const float4*>(a + (size_t)i * 8 + 4 * hf);
+            mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z); mx[3] = fmaxf(mx[3], v.w);
+        }
+    for (int i = i0; i < i1; ++i)
+        if (roa[i] == r) {
+            const float4 v = *reinterpret_cast<const float4*>(a + (size_t)i * 8 + 4 * hf);
+            den[0] += expf(v.x - mx[0]); den[1] += expf(v.y - mx[1]); den[2] += expf(v.z - mx[2]); den[3] += expf(v.w - mx[3]);
+        }
+    float aq[2] = {0.f, 0.f}, ap[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    for (int i = i0; i < i1; ++i)
+        if (roa[i] == r) {
+            const float4 v = *reinterpret_cast<const float4*>(a + (size_t)i * 8 + 4 * hf);
+            const float w[4] = {expf(v.x - mx[0]) / den[0], expf(v.y - mx[1]) / den[1], expf(v.z - mx[2]) / den[2], expf(v.w - mx[3]) / den[3]};
+            const float qv = q[(size_t)i * S + s];
+            const float pv[3] = {p[(size_t)i * 96 + s], p[(size_t)i * 96 + 32 + s], p[(size_t)i * 96 + 64 + s]};
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                aq[hh] += qv * w[2 * hh];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) ap[hh][x] += pv[x] * w[2 * hh + 1];
+            }
+        }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int h = 2 * hf + hh;
+        qh[s * PH + h] = aq[hh];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) ph[x][s * PH + h] = ap[hh][x];
+    }
+    __syncthreads();
+    // zdm on lanes 0..31, zdm_vec on all lanes (lane>>5 picks x = 0/1, then x = 2 by the first half)
+    float v = 0.0f;
+    if (hf == 0) hs[s] = elu(g32_linear(W, mw.zdm.l[0], qh, s));
+    __syncthreads();
+    if (hf == 0) v = elu(g32_linear(W, mw.zdm.l[1], hs, s));
+    __syncthreads();
+    if (hf == 0) hs[32 + s] = v;
+    __syncthreads();
+    float qrv = 0.0f;
+    if (hf == 0) qrv = g32_linear(W, mw.zdm.l[2], hs + 32, s);
+    const float pr0 = g32_linear(W, mw.zdm_vec, ph[hf], s);              // x = hf (0 or 1)
+    const float pr2 = hf == 0 ? g32_linear(W, mw.zdm_vec, ph[2], s) : 0.0f;
+    // gather the three components on the first half to take the norm
+    const float pr1 = __shfl(pr0, 32 + s);
+    if (hf == 0) {
+        zr[s] = qrv;
+        zr[32 + s] = sqrtf(pr0 * pr0 + pr1 * pr1 + pr2 * pr2);
+        if (qr_out) qr_out[(size_t)r * S + s] = qrv;
+        if (pr_out) { pr_out[(size_t)r * 96 + s] = pr0; pr_out[(size_t)r * 96 + 32 + s] = pr1; pr_out[(size_t)r * 96 + 64 + s] = pr2; }
+    }
+    __syncthreads();
+    if (mw.dm.depth == 3) {
+        if (hf == 0) hs[s] = elu(g32_linear(W, mw.dm.l[0], zr, s));
+        __syncthreads();
+        if (hf == 0) v = elu(g32_linear(W, mw.dm.l[1], hs, s));
+        __syncthreads();
+        if (hf == 0) hs[32 + s] = v;
+        __syncthreads();
+        if (hf == 0 && s < n_out) z_out[(size_t)r * n_out + s] = g32_linear(W, mw.dm.l[2], hs + 32, s);
+    } else {
+        if (hf == 0 && s < n_out) z_out[(size_t)r * n_out + s] = g32_linear(W, mw.dm.l[0], zr, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int n0, const float* q0, float* q_state) {
+    hipLaunchKernelGGL(k_embed, dim3((N + 7) / 8), dim3(256), 0, st, W, em, N, n0, q0, q_state);
+}
+
+void launch_unpack(hipStream_t st, int N, int k, const float* X, const void* ids, int ids_kind, int* ids_s, float4* geo,
+                   unsigned* dmax_bits, int* err_flag) {
+    const int64_t n1 = (int64_t)N * KMAX;
+    const dim3 grid1((unsigned)((n1 + 255) / 256)), grid2((unsigned)((n1 + KMAX + 255) / 256));
+    if (ids_kind == PESTO_IDS_INT64)
+        hipLaunchKernelGGL(k_unpack1<long long>, grid1, dim3(256), 0, st, N, k, X, (const long long*)ids, ids_s, geo, dmax_bits, err_flag);
+    else
+        hipLaunchKernelGGL(k_unpack1<int>, grid1, dim3(256), 0, st, N, k, X, (const int*)ids, ids_s, geo, dmax_bits, err_flag);
+    hipLaunchKernelGGL(k_unpack2, grid2, dim3(256), 0, st, N, ids_s, geo, dmax_bits);
+}
+
+void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,
+                 const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out) {
+    hipLaunchKernelGGL(k_seg_init, dim3((R + 255) / 256), dim3(256), 0, st, R, lo, hi);
+    hipLaunchKernelGGL(k_seg_bounds, dim3((N + 255) / 256), dim3(256), 0, st, N, R, roa, lo, hi, err_flag);
+    hipLaunchKernelGGL(k_pool_logits, dim3((N + 7) / 8), dim3(256), 0, st, W, mw.sam, N, q, p, a_tmp);
+    hipLaunchKernelGGL(k_pool_reduce, dim3(R), dim3(64), 0, st, W, mw, n_out, R, q, p, a_tmp, roa, lo, hi, qr_out, pr_out, z_out);
+}
+
+}  // namespace pesto

@@ -1,0 +1,239 @@
+"""Host mirror of the reference's ``Model`` (reference model/model.py:6-52) over the HIP C ABI.
+
+Drop-in usage, as in apply_model.ipynb:73-93,155:
+
+    from pesto_amd import Model, config_model
+    model = Model(config_model)
+    model.load_state_dict(torch.load(".../model_ckpt.pt", map_location="cpu"))
+    model = model.eval().to(device)
+    z = model(X, ids_topk, q, M.float())          # fp32 [R, N2], same kind/device as the inputs
+
+All arithmetic runs in libpesto_hip.so on the MI355X; there is no PyTorch or CPU fallback. ``device`` only
+says where the caller's tensors live: CUDA(ROCm) tensors are consumed in place on torch's current stream,
+CPU tensors / numpy arrays are staged through the library's own buffers.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .config import normalise
+from .topology import mask_to_segments
+from .weights import blob_schema, flatten_state_dict, unflatten_blob
+
+
+def _is_torch(x):
+    return hasattr(x, "detach") and hasattr(x, "device")
+
+
+class Model:
+    def __init__(self, config, device=None, validate=True):
+        self.config = normalise(config)
+        self._cc = _lib.make_c_config(self.config)
+        self._blob = None
+        self._handle = None
+        self._gpu = 0
+        self._io_device = None      # torch.device the caller asked for with .to(); informational
+        self.validate = validate    # check M (one residue per atom, none empty) on every call
+        self.training = False
+        if device is not None:
+            self.to(device)
+
+    # ------------------------------------------------------------------ torch.nn.Module-like surface
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference's state_dict (torch tensors or numpy arrays). Strict like torch's."""
+        self._blob = np.ascontiguousarray(flatten_state_dict(self.config, state_dict), dtype=np.float32)
+        self._release()
+        return "<All keys matched successfully>"
+
+    def state_dict(self):
+        if self._blob is None:
+            raise RuntimeError("no weights loaded")
+        return unflatten_blob(self.config, self._blob)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("pesto_amd.Model is inference-only (the reference's training loop is out of scope)")
+        return self
+
+    def to(self, device):
+        """``device``: 'cpu', 'cuda', 'cuda:1', torch.device, or an int GPU ordinal. 'cpu' keeps computing on GPU 0."""
+        idx = None
+        if isinstance(device, int):
+            idx = device
+        else:
+            s = str(device)
+            if s.startswith("cuda") and ":" in s:
+                idx = int(s.split(":")[1])
+            elif s.startswith("cuda"):
+                idx = 0
+                try:
+                    import torch
+                    if torch.cuda.is_available():
+                        idx = torch.cuda.current_device()
+                except Exception:
+                    pass
+            elif s != "cpu":
+                raise ValueError(f"unsupported device {device!r}")
+        self._io_device = device
+        if idx is not None and idx != self._gpu:
+            self._gpu = idx
+            self._release()
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    # ------------------------------------------------------------------ handle management
+    def _release(self):
+        if self._handle is not None:
+            _lib.load().pesto_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _ensure(self):
+        if self._handle is None:
+            if self._blob is None:
+                raise RuntimeError("load_state_dict() must be called before forward()")
+            lib = _lib.load()
+            h = ctypes.c_void_p()
+            _lib.check(lib.pesto_create(ctypes.byref(self._cc), self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size,
+                                        self._gpu, ctypes.byref(h)))
+            self._handle = h
+        return self._handle
+
+    @property
+    def handle(self):
+        return self._ensure()
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, X, ids_topk, q0, M):
+        """z = forward(X [N,3] f32, ids_topk [N,k] int (1-based, 0 = sink), q0 [N,N0] f32, M [N,R] 0/1) -> [R,N2] f32"""
+        if self.validate:
+            roa, R = mask_to_segments(M)
+        elif _is_torch(M):
+            import torch
+            R = int(M.shape[1])
+            roa = M.argmax(dim=1).to(torch.int32)
+        else:
+            R = int(M.shape[1])
+            roa = np.asarray(M).argmax(1).astype(np.int32)
+        return self.forward_segments(X, ids_topk, q0, roa, R)
+
+    __call__ = forward
+
+    def forward_segments(self, X, ids_topk, q0, res_of_atom, R):
+        """Same as forward() with the residue mask given as res_of_atom [N] int32 (column index per atom)."""
+        h = self._ensure()
+        lib = _lib.load()
+        n0 = self.config["em"]["N0"]
+        n_out = self.config["dm"]["N2"]
+        if _is_torch(X) and X.is_cuda:
+            import torch
+            if X.device.index != self._gpu:
+                raise RuntimeError(f"inputs are on cuda:{X.device.index} but the model is on cuda:{self._gpu} (use .to())")
+            Xc = X.detach().to(torch.float32).contiguous()
+            ids = ids_topk.detach()
+            if ids.dtype not in (torch.int32, torch.int64):
+                ids = ids.to(torch.int64)
+            ids = ids.contiguous()
+            qc = q0.detach().to(torch.float32).contiguous()
+            roa = res_of_atom if _is_torch(res_of_atom) else torch.as_tensor(np.asarray(res_of_atom), device=X.device)
+            roa = roa.to(device=X.device, dtype=torch.int32).contiguous()
+            N, k = ids.shape
+            self._check_shapes(N, Xc.shape, qc.shape, roa.shape, n0)
+            z = torch.empty((R, n_out), dtype=torch.float32, device=X.device)
+            stream = torch.cuda.current_stream(X.device).cuda_stream
+            _lib.check(lib.pesto_forward(h, N, R, k, Xc.data_ptr(), ids.data_ptr(),
+                                         _lib.IDS_INT64 if ids.dtype == torch.int64 else _lib.IDS_INT32,
+                                         qc.data_ptr(), roa.data_ptr(), z.data_ptr(), _lib.PTR_DEVICE, stream))
+            return z
+        # host path: CPU torch tensors or numpy arrays
+        as_torch = _is_torch(X)
+        Xn = np.ascontiguousarray(X.detach().numpy() if as_torch else X, dtype=np.float32)
+        idn = ids_topk.detach().numpy() if _is_torch(ids_topk) else np.asarray(ids_topk)
+        if idn.dtype not in (np.int32, np.int64):
+            idn = idn.astype(np.int64)
+        idn = np.ascontiguousarray(idn)
+        qn = np.ascontiguousarray(q0.detach().numpy() if _is_torch(q0) else q0, dtype=np.float32)
+        roa = np.ascontiguousarray(res_of_atom.detach().cpu().numpy() if _is_torch(res_of_atom) else res_of_atom, dtype=np.int32)
+        N, k = idn.shape
+        self._check_shapes(N, Xn.shape, qn.shape, roa.shape, n0)
+        z = np.empty((R, n_out), dtype=np.float32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(lib.pesto_forward(h, N, R, k, p(Xn), p(idn), _lib.IDS_INT64 if idn.dtype == np.int64 else _lib.IDS_INT32,
+                                     p(qn), p(roa), p(z), _lib.PTR_HOST, None))
+        if as_torch:
+            import torch
+            return torch.from_numpy(z)
+        return z
+
+    @staticmethod
+    def _check_shapes(N, xs, qs, rs, n0):
+        if tuple(xs) != (N, 3):
+            raise ValueError(f"X must be [N,3] with N={N}, got {tuple(xs)}")
+        if tuple(qs) != (N, n0):
+            raise ValueError(f"q0 must be [N,{n0}], got {tuple(qs)}")
+        if tuple(rs) != (N,):
+            raise ValueError(f"residue mask must cover N={N} atoms, got {tuple(rs)}")
+
+    # ------------------------------------------------------------------ per-stage access (tests)
+    def stage_embed(self, q0):
+        q0 = np.ascontiguousarray(q0, np.float32)
+        out = np.empty((q0.shape[0], 32), np.float32)
+        _lib.check(_lib.load().pesto_stage_embed(self._ensure(), q0.shape[0], q0.ctypes.data, out.ctypes.data))
+        return out
+
+    def stage_unpack(self, X, ids_topk):
+        X = np.ascontiguousarray(X, np.float32)
+        ids = np.ascontiguousarray(ids_topk)
+        kind = _lib.IDS_INT64 if ids.dtype == np.int64 else _lib.IDS_INT32
+        if kind == _lib.IDS_INT32:
+            ids = np.ascontiguousarray(ids, np.int32)
+        n, k = ids.shape
+        D = np.empty((n + 1, k), np.float32)
+        R = np.empty((n + 1, k, 3), np.float32)
+        _lib.check(_lib.load().pesto_stage_unpack(self._ensure(), n, k, X.ctypes.data, ids.ctypes.data, kind, D.ctypes.data, R.ctypes.data))
+        return D, R
+
+    def stage_layer(self, layer, q, p):
+        q = np.ascontiguousarray(q, np.float32).copy()
+        p = np.ascontiguousarray(p, np.float32).copy()
+        _lib.check(_lib.load().pesto_stage_layer(self._ensure(), layer, q.ctypes.data, p.ctypes.data))
+        return q, p
+
+    def stage_pool(self, q, p, res_of_atom, R):
+        q = np.ascontiguousarray(q, np.float32)
+        p = np.ascontiguousarray(p, np.float32)
+        roa = np.ascontiguousarray(res_of_atom, np.int32)
+        qr = np.empty((R, 32), np.float32)
+        pr = np.empty((R, 3, 32), np.float32)
+        z = np.empty((R, self.config["dm"]["N2"]), np.float32)
+        _lib.check(_lib.load().pesto_stage_pool(self._ensure(), q.shape[0], R, q.ctypes.data, p.ctypes.data, roa.ctypes.data,
+                                               qr.ctypes.data, pr.ctypes.data, z.ctypes.data))
+        return qr, pr, z
+
+    # ------------------------------------------------------------------ timing hooks (bench.py)
+    def set_timing(self, enabled=True):
+        _lib.check(_lib.load().pesto_set_timing(self._ensure(), 1 if enabled else 0))
+
+    def get_timing(self):
+        a, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+        _lib.check(_lib.load().pesto_get_timing(self._ensure(), ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
+        return {"layers_ms": a.value, "total_ms": b.value, "n_layer_launches": n.value}
+
+    def synchronize(self):
+        _lib.check(_lib.load().pesto_synchronize(self._ensure()))
+
+
+def blob_keys(config):
+    return [k for k, _ in blob_schema(config)]

@@ -1,0 +1,152 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against (a) golden vectors captured from the
+reference PyTorch CPU path and (b) the CPU oracle on the same seeded inputs.
+Tolerances: per-stage 1e-5 abs, whole forward 1e-4 abs on z (the north-star's fp32 bound)."""
+import numpy as np
+import pytest
+
+from conftest import golden, onehot, weights
+from pesto_amd.config import CONFIGS
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(tag):
+    from pesto_amd import Model
+    m = Model(CONFIGS[tag])
+    m.load_state_dict(weights(tag))
+    return m.eval()
+
+
+def _oracle(tag):
+    from oracle import oracle
+    return oracle.OracleModel(CONFIGS[tag], weights(tag))
+
+
+def test_stage_embed_unpack():
+    g = golden("ops_i_v4_0_crop200")
+    m = _model("i_v4_0")
+    q = m.stage_embed(onehot(g["em_in_idx"], 30))
+    assert np.abs(q - g["em_out"]).max() < 1e-6
+    for ids in (g["ids_topk"].astype(np.int32), g["ids_topk"].astype(np.int64)):
+        D, R = m.stage_unpack(g["X"], ids)
+        assert np.abs(D - g["D_nn"]).max() < 1e-5
+        assert np.abs(R - g["R_nn"]).max() < 1e-6
+        assert np.all(D[0] == 0) and np.all(R[0] == 0)
+
+
+@pytest.mark.parametrize("layer", [0, 3, 4, 8, 12, 15])
+def test_stage_layer(layer):
+    g = golden("ops_i_v4_0_crop200")
+    m = _model("i_v4_0")
+    m.stage_unpack(g["X"], g["ids_topk"].astype(np.int32))
+    q, p = m.stage_layer(layer, g[f"L{layer}_q_in"], g[f"L{layer}_p_in"])
+    assert np.abs(q - g[f"L{layer}_q_out"]).max() < 1e-5
+    assert np.abs(p - g[f"L{layer}_p_out"]).max() < 1e-5
+    assert np.all(q[0] == 0) and np.all(p[0] == 0)
+
+
+def test_stage_pool_decode():
+    g = golden("ops_i_v4_0_crop200")
+    m = _model("i_v4_0")
+    roa = g["res_of_atom"]
+    qr, pr, z = m.stage_pool(g["L15_q_out"][1:], g["L15_p_out"][1:], roa, int(roa.max()) + 1)
+    assert np.abs(qr - g["pool_qr"]).max() < 1e-5
+    assert np.abs(pr - g["pool_pr"]).max() < 1e-5
+    assert np.abs(z - g["z"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag,fixture", [
+    ("i_v4_0", "fwd_i_v4_0_2CUA"), ("i_v4_0", "fwd_i_v4_0_2AYO"), ("i_v3_0", "fwd_i_v3_0_2CUA"), ("i_v3_1", "fwd_i_v3_1h_2CUA"),
+    ("i_v4_0", "edge_n40"), ("i_v4_0", "edge_batch2"), ("i_v4_0", "edge_coincident"), ("i_v4_0", "edge_single_atom_residue"),
+])
+def test_forward_golden(tag, fixture):
+    g = golden(fixture)
+    m = _model(tag)
+    roa = g["res_of_atom"]
+    z = m.forward_segments(g["X"], g["ids_topk"].astype(np.int64), onehot(g["q_idx"], CONFIGS[tag]["em"]["N0"]), roa, int(roa.max()) + 1)
+    assert z.shape == g["z"].shape and np.isfinite(z).all()
+    assert np.abs(z - g["z"]).max() < 1e-4
+
+
+def test_forward_i_v4_1_32_layers():
+    """BASELINE configs 1 and 2 geometry with the i_v4_1 architecture (stacked real weights)."""
+    from pesto_amd.topology import mask_to_segments, synthetic_structure
+    m = _model("i_v4_1")
+    for inputs, out in (("fwd_i_v4_0_2CUA", "fwd_i_v4_1_stacked_2CUA"), ("fwd_i_v4_0_2AYO", "fwd_i_v4_1_stacked_2AYO")):
+        g = golden(inputs)
+        roa = g["res_of_atom"]
+        z = m.forward_segments(g["X"], g["ids_topk"], onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
+        assert np.abs(z - golden(out)["z"]).max() < 1e-4
+    for n in (512, 3000):
+        gs = golden(f"fwd_i_v4_1_stacked_synth{n}")
+        X, _, q, M = synthetic_structure(n, int(gs["seed"]))
+        roa, R = mask_to_segments(M)
+        z = m.forward_segments(X, gs["ids_topk"].astype(np.int32), q, roa, R)
+        assert np.abs(z - gs["z"]).max() < 1e-4
+
+
+def test_reference_call_signature_torch_cpu_and_device():
+    """Model(config).forward(X, ids_topk, q, M) with torch tensors, CPU and ROCm, as apply_model.ipynb:155 calls it."""
+    import torch
+    g = golden("fwd_i_v4_0_2CUA")
+    roa = g["res_of_atom"]
+    R = int(roa.max()) + 1
+    M = np.zeros((roa.size, R), np.float32)
+    M[np.arange(roa.size), roa] = 1
+    args = [torch.from_numpy(g["X"]), torch.from_numpy(g["ids_topk"].astype(np.int64)), torch.from_numpy(onehot(g["q_idx"], 30)), torch.from_numpy(M)]
+    m = _model("i_v4_0")
+    z_cpu = m(*args)
+    assert isinstance(z_cpu, torch.Tensor) and z_cpu.device.type == "cpu"
+    assert (z_cpu - torch.from_numpy(g["z"])).abs().max() < 1e-4
+    dev = torch.device("cuda:0")
+    m = m.to(dev)
+    z_dev = m(*[a.to(dev) for a in args])
+    assert z_dev.is_cuda and z_dev.dtype == torch.float32
+    assert torch.equal(z_dev.cpu(), z_cpu)     # same kernels, same order -> bitwise
+    # a side stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        z2 = m(*[a.to(dev) for a in args])
+    s.synchronize()
+    assert torch.equal(z2.cpu(), z_cpu)
+
+
+def test_oracle_vs_hip_seeded_random_structures():
+    """HIP path vs the CPU oracle on seeded synthetic clouds of ragged sizes, batched (block-diagonal collation)."""
+    from pesto_amd.topology import collate_batch_features, mask_to_segments, synthetic_structure
+    m, o = _model("i_v4_0"), _oracle("i_v4_0")
+    batch = [list(synthetic_structure(n, seed)) for n, seed in ((65, 1), (130, 2), (257, 3))]
+    X, ids, q, M = collate_batch_features(batch)
+    roa, R = mask_to_segments(M)
+    z_h = m.forward_segments(X, ids, q, roa, R)
+    z_o = o.forward_segments(X, ids, q, roa, R)
+    assert np.abs(z_h - z_o).max() < 1e-4
+
+
+def test_rotation_translation_invariance():
+    """Oracle-free property the reference holds to 2.1e-5: rigid motion of X, same ids -> same z."""
+    from pesto_amd.topology import mask_to_segments, synthetic_structure
+    m = _model("i_v4_0")
+    X, ids, q, M = synthetic_structure(600, 9)
+    ids1 = ids + 1
+    roa, R = mask_to_segments(M)
+    z0 = m.forward_segments(X, ids1, q, roa, R)
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    X2 = (X.astype(np.float64) @ Q.T + np.array([11.0, -7.0, 3.0])).astype(np.float32)
+    z1 = m.forward_segments(X2, ids1, q, roa, R)
+    assert np.abs(z0 - z1).max() < 1e-4
+
+
+def test_bad_inputs_raise():
+    from pesto_amd._lib import PestoError
+    g = golden("edge_n40")
+    m = _model("i_v4_0")
+    roa = g["res_of_atom"]
+    ids = g["ids_topk"].astype(np.int64).copy()
+    ids[3, 2] = 1000
+    with pytest.raises(PestoError):
+        m.forward_segments(g["X"], ids, onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
+    # the handle survives a failed structure (interfaceome/apply_model.py:57-82 skips and continues)
+    z = m.forward_segments(g["X"], g["ids_topk"], onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
+    assert np.abs(z - g["z"]).max() < 1e-4
