@@ -66,8 +66,9 @@ int pesto_destroy(pesto_model* m);
 
 /* replaces: Model.forward(X, ids_topk, q0, M)  (model/model.py:32-52).
  * ptr_kind: PESTO_PTR_HOST (library stages H2D/D2H itself) or PESTO_PTR_DEVICE (all five buffers on
- * the model's device). stream: a hipStream_t (NULL = the model's own stream). With device pointers the
- * call is asynchronous on `stream`; with host pointers it returns after z has been copied back.
+ * the model's device). stream: a hipStream_t. With device pointers the call is asynchronous on exactly
+ * that stream (NULL = HIP's default stream, which is what torch.cuda.current_stream() is by default);
+ * with host pointers NULL selects the model's own stream and the call returns after z has been copied back.
  * No allocation happens on this path once the grow-only workspace has seen a batch of this size. */
 int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k,
                   const float* X, const void* ids_topk, int32_t ids_kind,

@@ -62,6 +62,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PestoError(f"{LIB_PATH} not found: build it with `python -m pesto_amd.csrc.build` "
                          "(there is no CPU/PyTorch fallback for the forward pass)")
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64. If this
+    # library pulled in /opt/rocm's copy first, torch would later load a second runtime and one of the two
+    # would see no device. Importing torch first makes the dynamic loader resolve our DT_NEEDED
+    # libamdhip64.so.7 to the copy torch already mapped (SONAME match).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     c_p, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     P = ctypes.POINTER

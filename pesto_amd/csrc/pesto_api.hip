@@ -230,10 +230,10 @@ int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k, const float* 
     if (!X || !ids_topk || !q0 || !res_of_atom || !z_out) return fail(PESTO_ERR_INVALID, "null buffer");
     HIP_TRY(hipSetDevice(m->device));
     if (int rc = ensure_workspace(m, N, R)) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
-    if (ptr_kind == PESTO_PTR_DEVICE)
-        return run_forward(m, st, N, R, k, X, ids_topk, ids_kind, q0, res_of_atom, z_out, nullptr, nullptr);
+    if (ptr_kind == PESTO_PTR_DEVICE)   // stream is taken literally: NULL is HIP's default (null) stream
+        return run_forward(m, (hipStream_t)stream, N, R, k, X, ids_topk, ids_kind, q0, res_of_atom, z_out, nullptr, nullptr);
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     if (ptr_kind != PESTO_PTR_HOST) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
     if (m->in_X.ensure((size_t)N * 3 * 4) || m->in_ids.ensure((size_t)N * k * id_sz) || m->in_q0.ensure((size_t)N * m->cfg.n0 * 4) ||
         m->in_roa.ensure((size_t)N * 4))
