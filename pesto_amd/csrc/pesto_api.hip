@@ -58,6 +58,9 @@ struct pesto_model {
     float* W = nullptr;             // device weight image
     // workspace (library owns weights + a grow-only workspace; no allocation once warm)
     DevBuf ids_s, geo, q_a, p_a, q_b, p_b, pool_a, seg, z, flags;
+    DevBuf rec_nb, rec_cen, zrec;          // MFMA path: per-atom neighbour / centre records and attention sums
+    int impl = 2;                          // 2 = MFMA layer (default), 1 = LDS-tiled VALU layer (PESTO_IMPL=v1)
+    int edge_blocks = 512;                 // persistent workgroups of the edge kernel (2 per CU)
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     // state left by pesto_stage_unpack for pesto_stage_layer
     int64_t stage_N = -1;
@@ -72,7 +75,8 @@ namespace {
 
 size_t ws_bytes(int64_t N, int64_t R) {
     const size_t N1 = (size_t)N + 1;
-    return N1 * KMAX * 4 + N1 * KMAX * 16 + 2 * (N1 * S * 4 + N1 * 96 * 4) + (size_t)N * 8 * 4 + (size_t)R * 8 + (size_t)R * 32 * 4 + 64;
+    return N1 * KMAX * 4 + N1 * KMAX * 16 + 2 * (N1 * S * 4 + N1 * 96 * 4) + (size_t)N * 8 * 4 + (size_t)R * 8 + (size_t)R * 32 * 4 + 64 +
+           N1 * (REC_NB + REC_CEN + REC_Z) * 4;
 }
 
 int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
@@ -88,6 +92,11 @@ int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
     rc |= m->seg.ensure((size_t)(R > 0 ? R : 1) * 2 * sizeof(int));
     rc |= m->z.ensure((size_t)(R > 0 ? R : 1) * 32 * sizeof(float));
     rc |= m->flags.ensure(64);
+    if (m->impl == 2) {
+        rc |= m->rec_nb.ensure(N1 * REC_NB * sizeof(float));
+        rc |= m->rec_cen.ensure(N1 * REC_CEN * sizeof(float));
+        rc |= m->zrec.ensure(N1 * REC_Z * sizeof(float));
+    }
     return rc ? fail(PESTO_ERR_NOMEM, "device workspace allocation failed for N=%lld R=%lld", (long long)N, (long long)R) : 0;
 }
 
@@ -118,11 +127,27 @@ int run_forward(pesto_model* m, hipStream_t st, int64_t N, int64_t R, int k, con
     launch_unpack(st, (int)N, k, X, ids, ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(), dmax_ptr(m), err_ptr(m));
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[1], st));
     int cur = 0;
-    for (int l = 0; l < m->cfg.n_layers; ++l) {
-        launch_layer_v1(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), q[cur], p[cur], q[cur ^ 1], p[cur ^ 1]);
-        cur ^= 1;
+    if (m->impl == 2) {
+        // per layer: node kernel (finish layer l-1, write layer l's records) then edge kernel; state updated in place
+        for (int l = 0; l < m->cfg.n_layers; ++l) {
+            launch_node(st, m->W, l > 0 ? &m->img.layers[l - 1] : nullptr, &m->img.layers[l], N1, q[0], p[0], m->zrec.as<float>(),
+                        m->rec_nb.as<float>(), m->rec_cen.as<float>());
+            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(),
+                        m->rec_cen.as<float>(), m->zrec.as<float>(), m->edge_blocks);
+        }
+        launch_node(st, m->W, &m->img.layers[m->cfg.n_layers - 1], nullptr, N1, q[0], p[0], m->zrec.as<float>(), m->rec_nb.as<float>(),
+                    m->rec_cen.as<float>());
+    } else {
+        for (int l = 0; l < m->cfg.n_layers; ++l) {
+            launch_layer_v1(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), q[cur], p[cur], q[cur ^ 1], p[cur ^ 1]);
+            cur ^= 1;
+        }
     }
-    if (m->timing) { HIP_TRY(hipEventRecord(m->ev[2], st)); m->n_layer_launches = m->cfg.n_layers; m->have_timing = true; }
+    if (m->timing) {
+        HIP_TRY(hipEventRecord(m->ev[2], st));
+        m->n_layer_launches = m->impl == 2 ? 2 * m->cfg.n_layers + 1 : m->cfg.n_layers;
+        m->have_timing = true;
+    }
     launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)N, (int)R, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
                 m->seg.as<int>(), m->seg.as<int>() + R, err_ptr(m), qr_out, pr_out, z_out);
     HIP_TRY(hipGetLastError());
@@ -158,6 +183,8 @@ int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weight
     m->cfg = *cfg;
     m->device = device;
     m->img = build_device_image(*cfg, weights);
+    if (const char* impl = getenv("PESTO_IMPL")) m->impl = (strcmp(impl, "v1") == 0 || strcmp(impl, "1") == 0) ? 1 : 2;
+    if (const char* eb = getenv("PESTO_EDGE_BLOCKS")) { int v = atoi(eb); if (v > 0) m->edge_blocks = v; }
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&m->W, m->img.data.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(m->W, m->img.data.data(), m->img.data.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -178,7 +205,7 @@ int pesto_destroy(pesto_model* m) {
     for (auto& e : m->ev) if (e) hipEventDestroy(e);
     if (m->W) hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
-                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa})
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec})
         b->release();
     delete m;
     return 0;
@@ -303,11 +330,20 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
     hipStream_t st = m->stream;
     HIP_TRY(hipMemcpyAsync(m->q_a.p, q_io, N1 * S * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->p_a.p, p_io, N1 * 96 * 4, hipMemcpyHostToDevice, st));
-    launch_layer_v1(st, m->W, m->img.layers[layer], (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->q_a.as<float>(), m->p_a.as<float>(),
-                    m->q_b.as<float>(), m->p_b.as<float>());
+    const void *q_res = m->q_b.p, *p_res = m->p_b.p;
+    if (m->impl == 2) {
+        const LayerW* L = &m->img.layers[layer];
+        launch_node(st, m->W, nullptr, L, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>());
+        launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->zrec.as<float>(), m->edge_blocks);
+        launch_node(st, m->W, L, nullptr, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>());
+        q_res = m->q_a.p; p_res = m->p_a.p;
+    } else {
+        launch_layer_v1(st, m->W, m->img.layers[layer], (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->q_a.as<float>(), m->p_a.as<float>(),
+                        m->q_b.as<float>(), m->p_b.as<float>());
+    }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(q_io, m->q_b.p, N1 * S * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(p_io, m->p_b.p, N1 * 96 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(q_io, q_res, N1 * S * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(p_io, p_res, N1 * 96 * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }

@@ -1,0 +1,487 @@
+// pesto_layer_mfma.hip - the state-update layer on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+//
+// Reference math: src/model_operations.py:87-154 (StateUpdate.forward) + :225-242 (StateUpdateLayer.forward).
+// One layer = two kernels:
+//
+//   k_node   per ATOM, batched as MFMA GEMMs over 16-atom column tiles (one wave each):
+//            (finish) q += qpm(Zq), p += ppm(Zp) of the previous layer, sink row reset            (:147-152, :239-240)
+//            (prep)   the first Linear of the three edge MLPs is linear in its 193 inputs
+//                     [d | X_n(i) | q_j | |p_j| | p_i.r | p_j.r]  (:109-116), so its per-atom pieces are computed
+//                     ONCE per atom instead of once per edge (exact algebra, different summation order):
+//                       centre record   U_i = b1 + W[:,1:65] X_n(i),  G_i[c] = W[:,129:161] p_i[c],  Q_i = nqm(X_n(i))
+//                       neighbour record A_j = W[:,65:129] X_n(j),    C_j[c] = W[:,161:193] p_j[c],  p_j
+//   k_edge   per EDGE: h1 = ELU(U_i + w_d d + A_j + sum_c r_c (G_i[c] + C_j[c]))  (VALU + one small MFMA for the
+//            centre terms), layers 2/3 of eqkm/epkm/evm as MFMA chains held in registers, both softmaxes with
+//            wavefront shuffles, attention-weighted sums Zq/Zp written per atom.  (:119-144)
+//
+// MFMA conventions (16x16x4 f32): lane l = (c = l & 15, g = l >> 4).  D[4g + r][c] is register r of lane l.
+// Operands chain without shuffles: a D tile of features (rows 16fb + 4g + r) x edges (cols c) is fed back as the
+// B operand (or as the A operand, edges as rows) of the next layer with k-step (fb, r) carrying feature
+// 16fb + 4g + r from lane group g; weight fragments are stored to match: lane (o, kg) holds W[o][16fb + 4kg + r].
+#include <hip/hip_runtime.h>
+
+#include "pesto_kernels.h"
+
+namespace pesto {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+__device__ __forceinline__ f32x4 elu4(f32x4 v) { return f32x4{elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3])}; }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// acc[m] += W[m-block][fb-block] * x for the four k-steps r of block fb; frag table [m][fb][lane][r] in `wf`
+template <int NFB>
+__device__ __forceinline__ f32x4 mfma_block(const float* __restrict__ wf, int m, int fb, int lane, f32x4 x, f32x4 acc) {
+    const f32x4 w = ld4(wf + ((size_t)(m * NFB + fb) * 64 + lane) * 4);
+    acc = MFMA(w[0], x[0], acc);
+    acc = MFMA(w[1], x[1], acc);
+    acc = MFMA(w[2], x[2], acc);
+    acc = MFMA(w[3], x[3], acc);
+    return acc;
+}
+
+// =============================================================================================== node kernel
+// finish >= 0: apply layer `finish`'s output MLPs to Z and update the state in place (sink reset).
+// prep   >= 0: write layer `prep`'s centre / neighbour records from the (updated) state.
+// One wave = 16 atoms; lane (e = atom in tile, g).  Weight fragments stream from L2 (shared by all waves).
+__global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
+                                              int N1, float* __restrict__ q_state, float* __restrict__ p_state,
+                                              const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen) {
+    const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 16 >= N1) return;
+    const int i_raw = tile * 16 + e;
+    const bool valid = i_raw < N1;
+    const int i = valid ? i_raw : N1 - 1;
+
+    // state in B/D layout: q[m] = q[i][16m + 4g .. +3], p[c][m] likewise
+    f32x4 q[2], p[3][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        q[m] = ld4(q_state + (size_t)i * S + 16 * m + 4 * g);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c][m] = ld4(p_state + (size_t)i * 96 + c * 32 + 16 * m + 4 * g);
+    }
+
+    if (do_finish) {
+        const float* zr = Z + (size_t)i * REC_Z;
+        // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147)
+        f32x4 h[2], t[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) h[m] = ld4(W + wf_.n_bq0 + 16 * m + 4 * g);
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            const f32x4 x = ld4(zr + 16 * fb + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) h[m] = mfma_block<4>(W + wf_.n_q0, m, fb, lane, x, h[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { h[m] = elu4(h[m]); t[m] = ld4(W + wf_.n_bq1 + 16 * m + 4 * g); }
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) t[m] = mfma_block<2>(W + wf_.n_q1, m, fb, lane, h[fb], t[m]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { t[m] = elu4(t[m]); h[m] = ld4(W + wf_.n_bq2 + 16 * m + 4 * g); }
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) h[m] = mfma_block<2>(W + wf_.n_q2, m, fb, lane, t[fb], h[m]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) q[m] += h[m];                                                  // :151
+        // ppm: 64 -> 32, no bias, per xyz component                                              // :148, :152
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 a[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+                const f32x4 x = ld4(zr + 64 + c * 64 + 16 * fb + 4 * g);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[m] = mfma_block<4>(W + wf_.n_pp, m, fb, lane, x, a[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) p[c][m] += a[m];
+        }
+        if (i == 0) {                                                                              // :239-240 sink
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { q[m] = f32x4{0, 0, 0, 0}; p[0][m] = q[m]; p[1][m] = q[m]; p[2][m] = q[m]; }
+        }
+        if (valid) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                st4(q_state + (size_t)i * S + 16 * m + 4 * g, q[m]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) st4(p_state + (size_t)i * 96 + c * 32 + 16 * m + 4 * g, p[c][m]);
+            }
+        }
+    }
+    if (!do_prep) return;
+
+    // X_n = [q | |p|]  as four 16-feature blocks                                                  // :103-106
+    f32x4 xn[4];
+    xn[0] = q[0]; xn[1] = q[1];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            xn[2 + m][r] = sqrtf(p[0][m][r] * p[0][m][r] + p[1][m][r] * p[1][m][r] + p[2][m][r] * p[2][m][r]);
+
+    float* cen = rec_cen + (size_t)i * REC_CEN;
+    float* nb = rec_nb + (size_t)i * REC_NB;
+    // [U | A] = [W[:,1:65]; W[:,65:129]] X_n   (16 output blocks; U carries b1)
+#pragma unroll 4
+    for (int ob = 0; ob < 16; ++ob) {
+        f32x4 a = ob < 8 ? ld4(W + wp_.n_b1 + 16 * ob + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) a = mfma_block<4>(W + wp_.n_ua, ob, fb, lane, xn[fb], a);
+        if (valid) {
+            if (ob < 8) st4(cen + ob * 64 + 3 * 16 + 4 * g, a);                 // centre record slot kg = 3 (U)
+            else st4(nb + ((ob - 8) * 4 + g) * 16, a);                          // neighbour record array 0 (A)
+        }
+    }
+    // [G_c | C_c] = [W[:,129:161]; W[:,161:193]] p[c]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll 4
+        for (int ob = 0; ob < 16; ++ob) {
+            f32x4 a = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) a = mfma_block<2>(W + wp_.n_gc, ob, fb, lane, p[c][fb], a);
+            if (valid) {
+                if (ob < 8) st4(cen + ob * 64 + c * 16 + 4 * g, a);
+                else st4(nb + ((ob - 8) * 4 + g) * 16 + (1 + c) * 4, a);
+            }
+        }
+    }
+    // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12 (rows 12..15 of the last block are zero padding)   // :119
+    {
+        f32x4 h[2], t[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) h[m] = ld4(W + wp_.n_bn0 + 16 * m + 4 * g);
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) h[m] = mfma_block<4>(W + wp_.n_n0, m, fb, lane, xn[fb], h[m]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { h[m] = elu4(h[m]); t[m] = ld4(W + wp_.n_bn1 + 16 * m + 4 * g); }
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) t[m] = mfma_block<2>(W + wp_.n_n1, m, fb, lane, h[fb], t[m]);
+        f32x4 qq = ld4(W + wp_.n_bn2 + 4 * g);
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) qq = mfma_block<2>(W + wp_.n_n2, 0, fb, lane, elu4(t[fb]), qq);
+        if (valid) st4(cen + 512 + 4 * g, qq);
+    }
+    // copy of p for the neighbours' vector-value gather
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) st4(nb + 512 + c * 32 + 16 * m + 4 * g, p[c][m]);
+    }
+}
+
+// =============================================================================================== edge kernel
+struct EdgeWaveScratch {
+    int nb[64];          // neighbour id per row
+    float geo[4][64];    // r_hat x, y, z and d per row (SoA)
+    float wts[8][64];    // attention weights [h*4 + part][row]: part 0 scalar, 1..3 the vector chunks
+    float wsum[8][2];    // per centre: sum over edges of the part-2 weights (multiplies p_i)
+    float zbuf[2][256];  // Zq | Zp staging per centre (two centres per tile when NN == 8)
+};
+struct EdgeSmem {
+    float w[EDGE_LDS_FLOATS];
+    EdgeWaveScratch ws[4];
+};
+
+// first edge layer for feature block fb of one 16-edge tile: h1[r] = ELU(pre-activation of feature 16fb+4g+r, edge e)
+template <int NN>
+__device__ __forceinline__ f32x4 edge_l1(int fb, int lane, int g, const float* __restrict__ cenA, const float* __restrict__ cenB,
+                                         float bgA, float bgB, const float* __restrict__ recj, const float* __restrict__ wd,
+                                         float d, float rx, float ry, float rz) {
+    f32x4 acc = MFMA(cenA[fb * 64 + lane], bgA, (f32x4{0, 0, 0, 0}));          // sum_c G_i[c] r_c + U_i, centre A columns
+    if (NN == 8) acc = MFMA(cenB[fb * 64 + lane], bgB, acc);                   // second centre of the tile
+    const float* rp = recj + (fb * 4 + g) * 16;
+    const f32x4 a4 = ld4(rp), c0 = ld4(rp + 4), c1 = ld4(rp + 8), c2 = ld4(rp + 12);
+    const f32x4 w4 = ld4(wd + 16 * fb + 4 * g);
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = elu_f(acc[r] + a4[r] + d * w4[r] + rx * c0[r] + ry * c1[r] + rz * c2[r]);
+    return h;
+}
+
+template <int NN>
+__global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
+                                                 const int* __restrict__ ids_s, const float4* __restrict__ geo,
+                                                 const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
+                                                 float* __restrict__ Z) {
+    constexpr int A = 64 / NN;                 // centres per wave work item (64 edge rows)
+    constexpr int TPC = NN >= 16 ? NN / 16 : 1;   // tiles per centre
+    __shared__ EdgeSmem sm;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = lane & 15, g = lane >> 4;
+    {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
+        const f32x4* src = reinterpret_cast<const f32x4*>(W + lw.e_lds);
+        f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
+        for (int k = threadIdx.x; k < EDGE_LDS_FLOATS / 4; k += 256) dst[k] = src[k];
+    }
+    __syncthreads();
+    EdgeWaveScratch& ws = sm.ws[wave];
+    const float* w2f = sm.w + EL_W2F;
+    const float* w3k = sm.w + EL_W3K;
+    const float* w3v = sm.w + EL_W3V;
+    const float sdk = sqrtf((float)NK);
+
+    for (int work = blockIdx.x * 4 + wave; work < n_work; work += gridDim.x * 4) {
+        const int c0 = work * A;
+        {   // rows of this work item: lane = row
+            const int a = lane / NN, c = lane % NN, i = c0 + a;
+            const bool valid = i < N1;
+            ws.nb[lane] = valid ? ids_s[(size_t)i * KMAX + c] : 0;
+            const float4 gg = valid ? geo[(size_t)i * KMAX + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ws.geo[0][lane] = gg.x; ws.geo[1][lane] = gg.y; ws.geo[2][lane] = gg.z; ws.geo[3][lane] = gg.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ------------------------------------------------------------------ pass 1: keys -> logits (eqkm, epkm)
+        float lg[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 16 * t + e;
+            const int aA = NN == 8 ? 2 * t : (16 * t) / NN;            // centre(s) of this tile (local index)
+            const int iA = min(c0 + aA, N1 - 1), iB = min(c0 + aA + 1, N1 - 1);
+            const int aMine = NN == 8 ? aA + (e >> 3) : aA;
+            const int iMine = min(c0 + aMine, N1 - 1);
+            const float* cenA = rec_cen + (size_t)iA * REC_CEN;
+            const float* cenB = rec_cen + (size_t)iB * REC_CEN;
+            const float rx = ws.geo[0][row], ry = ws.geo[1][row], rz = ws.geo[2][row], d = ws.geo[3][row];
+            const float bg = g == 0 ? rx : (g == 1 ? ry : (g == 2 ? rz : 1.0f));
+            const float bgA = (NN == 8 && e >= 8) ? 0.0f : bg, bgB = (NN == 8 && e >= 8) ? bg : 0.0f;
+            const float* recj = rec_nb + (size_t)ws.nb[row] * REC_NB;
+            f32x4 acc2[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc2[m] = ld4(sm.w + EL_B2 + 16 * m + 4 * g);
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+                const f32x4 h1 = edge_l1<NN>(fb, lane, g, cenA, cenB, bgA, bgB, recj, sm.w + EL_WD, d, rx, ry, rz);
+                const int net = fb >> 1, fbl = fb & 1;
+#pragma unroll
+                for (int ml = 0; ml < 2; ++ml)
+                    acc2[net * 2 + ml] = mfma_block<2>(w2f + net * 4 * 256, ml, fbl, lane, h1, acc2[net * 2 + ml]);
+            }
+            f32x4 kacc = ld4(sm.w + EL_BK + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) kacc = mfma_block<4>(w3k, 0, m, lane, elu4(acc2[m]), kacc);
+            // lane (e, g): kacc[0..2] = key of part g for edge row; logits against Q[0] (scalar) or Q[1] (vector)
+            const float* Qv = rec_cen + (size_t)iMine * REC_CEN + 512 + (g == 0 ? 0 : 6);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                lg[t][h] = (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) / sdk;
+        }
+
+        // ------------------------------------------------------------------ softmax per centre  (:139-140)
+        // scalar: over the NN rows of part 0; vector: over the 3*NN slots of parts 1..3 together
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float mx[4], ex[4], sr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mx[t] = lg[t][h];
+            if (TPC == 4) { const float m = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])); mx[0] = mx[1] = mx[2] = mx[3] = m; }
+            if (TPC == 2) { const float m0 = fmaxf(mx[0], mx[1]), m1 = fmaxf(mx[2], mx[3]); mx[0] = mx[1] = m0; mx[2] = mx[3] = m1; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float m = mx[t];
+                if (NN >= 16) m = fmaxf(m, __shfl_xor(m, 8));
+                m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 1));
+                const float v1 = __shfl(m, 16 + e), v2 = __shfl(m, 32 + e), v3 = __shfl(m, 48 + e);
+                mx[t] = g == 0 ? m : fmaxf(v1, fmaxf(v2, v3));
+                ex[t] = __expf(lg[t][h] - mx[t]);
+                sr[t] = ex[t];
+            }
+            if (TPC == 4) { const float s = (sr[0] + sr[1]) + (sr[2] + sr[3]); sr[0] = sr[1] = sr[2] = sr[3] = s; }
+            if (TPC == 2) { const float s0 = sr[0] + sr[1], s1 = sr[2] + sr[3]; sr[0] = sr[1] = s0; sr[2] = sr[3] = s1; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float s = sr[t];
+                if (NN >= 16) s += __shfl_xor(s, 8);
+                s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+                const float s1 = __shfl(s, 16 + e), s2 = __shfl(s, 32 + e), s3 = __shfl(s, 48 + e);
+                const float tot = g == 0 ? s : (s1 + s2) + s3;
+                ws.wts[h * 4 + g][16 * t + e] = ex[t] / tot;
+                // centre-level sum of the part-2 weights (what multiplies p_i in Zp): written by the part-2 lanes
+                if (g == 2 && (NN == 8 ? (e & 7) == 0 : e == 0) && (t % TPC) == 0) {
+                    const int a = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
+                    ws.wsum[a][h] = s2 / ((s1 + s2) + s3);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ------------------------------------------------------------------ pass 2: values (evm) and the weighted sums
+        float zq[2][2], zp1[2][3][2], zp3[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { zq[h][k] = 0.f; zp3[h][k] = 0.f; zp1[h][0][k] = zp1[h][1][k] = zp1[h][2][k] = 0.f; }
+
+        for (int t = 0; t < 4; ++t) {
+            const int row = 16 * t + e;
+            const int aA = NN == 8 ? 2 * t : (16 * t) / NN;
+            const int iA = min(c0 + aA, N1 - 1), iB = min(c0 + aA + 1, N1 - 1);
+            const float* cenA = rec_cen + (size_t)iA * REC_CEN;
+            const float* cenB = rec_cen + (size_t)iB * REC_CEN;
+            const float rx = ws.geo[0][row], ry = ws.geo[1][row], rz = ws.geo[2][row], d = ws.geo[3][row];
+            const float bg = g == 0 ? rx : (g == 1 ? ry : (g == 2 ? rz : 1.0f));
+            const float bgA = (NN == 8 && e >= 8) ? 0.0f : bg, bgB = (NN == 8 && e >= 8) ? bg : 0.0f;
+            const float* recj = rec_nb + (size_t)ws.nb[row] * REC_NB;
+            f32x4 acc2[4];
+#pragma unroll
+            for (int ml = 0; ml < 4; ++ml) acc2[ml] = ld4(sm.w + EL_B2 + 64 + 16 * ml + 4 * g);
+#pragma unroll
+            for (int fbl = 0; fbl < 4; ++fbl) {
+                const f32x4 h1 = edge_l1<NN>(4 + fbl, lane, g, cenA, cenB, bgA, bgB, recj, sm.w + EL_WD, d, rx, ry, rz);
+#pragma unroll
+                for (int ml = 0; ml < 4; ++ml) acc2[ml] = mfma_block<4>(w2f + 8 * 256, ml, fbl, lane, h1, acc2[ml]);
+            }
+            f32x4 h2[4];
+#pragma unroll
+            for (int ml = 0; ml < 4; ++ml) h2[ml] = elu4(acc2[ml]);
+            // V[edge 16t + 4g + r][feature 16fo + e]: edges as rows (A operand = h2), weights as B operand
+            f32x4 v[4];
+#pragma unroll
+            for (int fo = 0; fo < 4; ++fo) {
+                const float b = sm.w[EL_B3V + 16 * fo + e];
+                v[fo] = f32x4{b, b, b, b};
+#pragma unroll
+                for (int ml = 0; ml < 4; ++ml) {
+                    const f32x4 wv = ld4(w3v + ((size_t)(fo * 4 + ml) * 64 + lane) * 4);
+                    v[fo] = MFMA(h2[ml][0], wv[0], v[fo]);
+                    v[fo] = MFMA(h2[ml][1], wv[1], v[fo]);
+                    v[fo] = MFMA(h2[ml][2], wv[2], v[fo]);
+                    v[fo] = MFMA(h2[ml][3], wv[3], v[fo]);
+                }
+            }
+            // attention-weighted sums over this lane's four edges (:143-144, first block of Vp :132)
+            const int r0 = 16 * t + 4 * g;
+            const f32x4 gx = ld4(&ws.geo[0][r0]), gy = ld4(&ws.geo[1][r0]), gz = ld4(&ws.geo[2][r0]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 wq = ld4(&ws.wts[h * 4 + 0][r0]), w1 = ld4(&ws.wts[h * 4 + 1][r0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    zq[h][0] += wq[r] * v[0][r];
+                    zq[h][1] += wq[r] * v[1][r];
+                    const float wx = w1[r] * gx[r], wy = w1[r] * gy[r], wz = w1[r] * gz[r];
+                    zp1[h][0][0] += wx * v[2][r]; zp1[h][0][1] += wx * v[3][r];
+                    zp1[h][1][0] += wy * v[2][r]; zp1[h][1][1] += wy * v[3][r];
+                    zp1[h][2][0] += wz * v[2][r]; zp1[h][2][1] += wz * v[3][r];
+                }
+            }
+            if ((t + 1) % TPC != 0) {   // centre continues in the next tile: only the p_j gather for this tile
+#pragma unroll 4
+                for (int ee = 0; ee < 16; ++ee) {
+                    const int rr = 16 * t + ee;
+                    const float* pj = rec_nb + (size_t)ws.nb[rr] * REC_NB + 512;
+                    const float p0 = pj[lane], p1 = lane < 32 ? pj[64 + lane] : 0.0f;
+                    const float w0 = ws.wts[3][rr], w1 = ws.wts[7][rr];
+                    zp3[0][0] += w0 * p0; zp3[0][1] += w0 * p1; zp3[1][0] += w1 * p0; zp3[1][1] += w1 * p1;
+                }
+                continue;
+            }
+            // ---- centre(s) complete: reduce the per-lane partial sums across lane groups, stage in LDS
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float x = zq[h][k];
+                    x += __shfl_xor(x, 16); if (NN >= 16) x += __shfl_xor(x, 32);
+                    zq[h][k] = x;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float y = zp1[h][c][k];
+                        y += __shfl_xor(y, 16); if (NN >= 16) y += __shfl_xor(y, 32);
+                        zp1[h][c][k] = y;
+                    }
+                }
+            if (g == 0 || (NN == 8 && g == 2)) {
+                float* zb = ws.zbuf[(NN == 8 && g == 2) ? 1 : 0];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        zb[h * 32 + 16 * k + e] = zq[h][k];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) zb[64 + c * 64 + h * 32 + 16 * k + e] = zp1[h][c][k];
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int sel = 0; sel < (NN == 8 ? 2 : 1); ++sel) {
+                const int a = NN == 8 ? 2 * t + sel : (16 * t) / NN;
+                const int i = c0 + a;
+                const int e0 = NN == 8 ? 8 * sel : 0, e1 = NN == 8 ? 8 * sel + 8 : 16;
+                for (int ee = e0; ee < e1; ++ee) {                      // third block of Vp: neighbours' p_j  (:134)
+                    const int rr = 16 * t + ee;
+                    const float* pj = rec_nb + (size_t)ws.nb[rr] * REC_NB + 512;
+                    const float p0 = pj[lane], p1 = lane < 32 ? pj[64 + lane] : 0.0f;
+                    const float w0 = ws.wts[3][rr], w1 = ws.wts[7][rr];
+                    zp3[0][0] += w0 * p0; zp3[0][1] += w0 * p1; zp3[1][0] += w1 * p0; zp3[1][1] += w1 * p1;
+                }
+                if (i < N1) {
+                    const float* zb = ws.zbuf[sel];
+                    const float* pi = rec_nb + (size_t)i * REC_NB + 512;       // second block of Vp: p_i  (:133)
+                    float* zo = Z + (size_t)i * REC_Z;
+                    zo[lane] = zb[lane];
+                    const int c = lane >> 5, s = lane & 31;
+                    const float pi0 = pi[lane];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        zo[64 + c * 64 + h * 32 + s] = zb[64 + c * 64 + h * 32 + s] + ws.wsum[a][h] * pi0 + zp3[h][0];
+                    if (lane < 32) {
+                        const float pi1 = pi[64 + lane];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            zo[64 + 128 + h * 32 + lane] = zb[64 + 128 + h * 32 + lane] + ws.wsum[a][h] * pi1 + zp3[h][1];
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { zp3[h][0] = 0.f; zp3[h][1] = 0.f; }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { zq[h][k] = 0.f; zp1[h][0][k] = zp1[h][1][k] = zp1[h][2][k] = 0.f; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// =============================================================================================== launchers
+void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
+                 const float* Z, float* rec_nb, float* rec_cen) {
+    const int tiles = (N1 + 15) / 16;
+    const LayerW dummy{};
+    hipLaunchKernelGGL(k_node, dim3((tiles + 3) / 4), dim3(256), 0, st, W, finish ? *finish : dummy, prep ? *prep : dummy,
+                       finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
+}
+
+void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
+                 const float* rec_nb, const float* rec_cen, float* Z, int max_blocks) {
+    const int A = 64 / lw.nn;
+    const int n_work = (N1 + A - 1) / A;
+    int blocks = (n_work + 3) / 4;
+    if (blocks > max_blocks) blocks = max_blocks;
+    const dim3 grid(blocks), block(256);
+    switch (lw.nn) {
+        case 8: hipLaunchKernelGGL(k_edge<8>, grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
+        case 16: hipLaunchKernelGGL(k_edge<16>, grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
+        case 32: hipLaunchKernelGGL(k_edge<32>, grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
+        default: hipLaunchKernelGGL(k_edge<64>, grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
+    }
+}
+
+}  // namespace pesto

@@ -60,6 +60,37 @@ MlpW put_mlp(std::vector<float>& img, const float* blob, const HostMlp& m) {
     return d;
 }
 void pad16(std::vector<float>& img) { while (img.size() % 4) img.push_back(0.0f); }
+
+// A dense row-major matrix view W[rows][cols] assembled from pieces of the blob (zero outside)
+struct Mat {
+    int rows, cols;
+    std::vector<float> v;
+    Mat(int r, int c) : rows(r), cols(c), v((size_t)r * c, 0.0f) {}
+    float& at(int r, int c) { return v[(size_t)r * cols + c]; }
+    float get(int r, int c) const { return (r < rows && c < cols) ? v[(size_t)r * cols + c] : 0.0f; }
+};
+// copy torch weight W[out][in] columns [c0, c0+nc) of rows [0, n_out) into M at (r0, k0)
+void put_block(Mat& M, int r0, int k0, const float* blob, const HostLinear& l, int c0, int nc, int row_lo = 0, int row_n = -1) {
+    if (row_n < 0) row_n = l.n_out;
+    for (int o = 0; o < row_n; ++o)
+        for (int c = 0; c < nc; ++c) M.at(r0 + o, k0 + c) = blob[l.w + (int64_t)(row_lo + o) * l.n_in + c0 + c];
+}
+// MFMA fragment table [m][fb][lane][r] of M (rows = out, cols = in), appended to img; returns offset
+int32_t put_frags(std::vector<float>& img, const Mat& M, int n_m, int n_fb, int row0 = 0, int col0 = 0) {
+    int32_t off = (int32_t)img.size();
+    for (int m = 0; m < n_m; ++m)
+        for (int fb = 0; fb < n_fb; ++fb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r)
+                    img.push_back(M.get(row0 + 16 * m + (lane & 15), col0 + 16 * fb + 4 * (lane >> 4) + r));
+    return off;
+}
+int32_t put_vec(std::vector<float>& img, const float* src, int n, int pad_to = 0) {
+    int32_t off = (int32_t)img.size();
+    img.insert(img.end(), src, src + n);
+    for (int i = n; i < pad_to; ++i) img.push_back(0.0f);
+    return off;
+}
 }  // namespace
 
 HostSchema host_schema(const pesto_config& c) {
@@ -98,7 +129,6 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
         const HostLayer& L = h.layers[l];
         LayerW& W = d.layers[l];
         W.nn = c.nn[l];
-        W.v2_base = -1;
         pad16(img);
         // edge layer 1: concatenated along out -> Wt1[193][128]
         W.w1 = (int32_t)img.size();
@@ -125,6 +155,77 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
         W.nqm = put_mlp(img, blob, L.nqm);
         W.qpm = put_mlp(img, blob, L.qpm);
         W.ppm = put_linear(img, blob, L.ppm);
+
+        // ---------------- MFMA path images
+        // W1cat[128][193]: rows 0-31 eqkm, 32-63 epkm, 64-127 evm (first Linear of each edge MLP)
+        Mat W1(128, XE);
+        std::vector<float> b1(128), b2(128);
+        for (int n = 0; n < 3; ++n) {
+            put_block(W1, col0[n], 0, blob, nets[n]->l[0], 0, XE);
+            for (int o = 0; o < nets[n]->l[0].n_out; ++o) b1[col0[n] + o] = blob[nets[n]->l[0].b + o];
+            for (int o = 0; o < nets[n]->l[1].n_out; ++o) b2[col0[n] + o] = blob[nets[n]->l[1].b + o];
+        }
+        pad16(img);
+        W.e_lds = (int32_t)img.size();
+        {   // edge layer 2 frags: eq 2x2, ep 2x2, ev 4x4
+            Mat Weq(32, 32), Wep(32, 32), Wev(64, 64);
+            put_block(Weq, 0, 0, blob, L.eqkm.l[1], 0, 32);
+            put_block(Wep, 0, 0, blob, L.epkm.l[1], 0, 32);
+            put_block(Wev, 0, 0, blob, L.evm.l[1], 0, 64);
+            put_frags(img, Weq, 2, 2); put_frags(img, Wep, 2, 2); put_frags(img, Wev, 4, 4);
+            // key rows: row 4*part + kappa; part 0 = eqkm out kappa (reads h2[0:32]); part 1..3 = epkm out 3(part-1)+kappa (h2[32:64])
+            Mat Wk(16, 64);
+            std::vector<float> bk(16, 0.0f);
+            for (int kap = 0; kap < 3; ++kap) {
+                for (int c = 0; c < 32; ++c) Wk.at(kap, c) = blob[L.eqkm.l[2].w + (int64_t)kap * 32 + c];
+                bk[kap] = blob[L.eqkm.l[2].b + kap];
+                for (int part = 1; part < 4; ++part) {
+                    const int o = 3 * (part - 1) + kap;
+                    for (int c = 0; c < 32; ++c) Wk.at(4 * part + kap, 32 + c) = blob[L.epkm.l[2].w + (int64_t)o * 32 + c];
+                    bk[4 * part + kap] = blob[L.epkm.l[2].b + o];
+                }
+            }
+            put_frags(img, Wk, 1, 4);
+            Mat Wv(64, 64);
+            put_block(Wv, 0, 0, blob, L.evm.l[2], 0, 64);
+            put_frags(img, Wv, 4, 4);               // [fo][m]
+            put_vec(img, b2.data(), 128);
+            put_vec(img, bk.data(), 16);
+            put_vec(img, blob + L.evm.l[2].b, 64);
+            std::vector<float> wd(128);
+            for (int f = 0; f < 128; ++f) wd[f] = W1.get(f, 0);
+            put_vec(img, wd.data(), 128);
+        }
+        // node kernel: finish (qpm, ppm)
+        {
+            Mat M0(32, 64), M1(32, 32), M2(32, 32), Mp(32, 64);
+            put_block(M0, 0, 0, blob, L.qpm.l[0], 0, 64);
+            put_block(M1, 0, 0, blob, L.qpm.l[1], 0, 32);
+            put_block(M2, 0, 0, blob, L.qpm.l[2], 0, 32);
+            put_block(Mp, 0, 0, blob, L.ppm, 0, 64);
+            W.n_q0 = put_frags(img, M0, 2, 4); W.n_bq0 = put_vec(img, blob + L.qpm.l[0].b, 32);
+            W.n_q1 = put_frags(img, M1, 2, 2); W.n_bq1 = put_vec(img, blob + L.qpm.l[1].b, 32);
+            W.n_q2 = put_frags(img, M2, 2, 2); W.n_bq2 = put_vec(img, blob + L.qpm.l[2].b, 32);
+            W.n_pp = put_frags(img, Mp, 2, 4);
+        }
+        // node kernel: records. [U|A]: rows 0-127 = W1[:, 1:65] (centre role), rows 128-255 = W1[:, 65:129] (neighbour role)
+        {
+            Mat Mua(256, 64), Mgc(256, 32);
+            for (int f = 0; f < 128; ++f)
+                for (int c = 0; c < 64; ++c) { Mua.at(f, c) = W1.get(f, 1 + c); Mua.at(128 + f, c) = W1.get(f, 65 + c); }
+            for (int f = 0; f < 128; ++f)
+                for (int c = 0; c < 32; ++c) { Mgc.at(f, c) = W1.get(f, 129 + c); Mgc.at(128 + f, c) = W1.get(f, 161 + c); }
+            W.n_ua = put_frags(img, Mua, 16, 4);
+            W.n_b1 = put_vec(img, b1.data(), 128);
+            W.n_gc = put_frags(img, Mgc, 16, 2);
+            Mat N0(32, 64), N1(32, 32), N2(16, 32);
+            put_block(N0, 0, 0, blob, L.nqm.l[0], 0, 64);
+            put_block(N1, 0, 0, blob, L.nqm.l[1], 0, 32);
+            put_block(N2, 0, 0, blob, L.nqm.l[2], 0, 32);
+            W.n_n0 = put_frags(img, N0, 2, 4); W.n_bn0 = put_vec(img, blob + L.nqm.l[0].b, 32);
+            W.n_n1 = put_frags(img, N1, 2, 2); W.n_bn1 = put_vec(img, blob + L.nqm.l[1].b, 32);
+            W.n_n2 = put_frags(img, N2, 1, 2); W.n_bn2 = put_vec(img, blob + L.nqm.l[2].b, 12, 16);
+        }
     }
     pad16(img);
     return d;

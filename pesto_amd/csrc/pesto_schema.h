@@ -34,9 +34,29 @@ struct LayerW {
     MlpW nqm, qpm;
     LinearW ppm;
     int32_t nn;
-    // ---- v2 (MFMA) images, filled by build_device_image_v2
-    int32_t v2_base;
+    // ---- MFMA path (pesto_layer_mfma.hip). "frag" tables are MFMA operand fragments in the order
+    // [out-block m][in-block fb][lane 0..63][r 0..3]: value W[16m + (lane&15)][16fb + 4(lane>>4) + r], so one
+    // float4 per lane feeds the four k-steps r of mfma_f32_16x16x4 for (m, fb).
+    int32_t e_lds;              // edge-kernel LDS image, EDGE_LDS_FLOATS contiguous floats (layout: EdgeLds below)
+    int32_t n_q0, n_bq0, n_q1, n_bq1, n_q2, n_bq2, n_pp;   // qpm frags [2][4],[2][2],[2][2] + biases[32]; ppm frags [2][4]
+    int32_t n_ua, n_b1, n_gc;                               // [U|A] frags [16][4], b1[128]; [G|C] frags [16][2]
+    int32_t n_n0, n_bn0, n_n1, n_bn1, n_n2, n_bn2;          // nqm frags [2][4],[2][2],[1][2] + biases (last padded to 16)
 };
+
+// edge-kernel LDS image (float offsets)
+constexpr int EL_W2F = 0;                 // 24 frags: eq (m,fb) 2x2, ep 2x2, ev 4x4
+constexpr int EL_W3K = EL_W2F + 24 * 256; // 4 frags: key rows arranged [part g][kappa], K = h2 blocks 0..3
+constexpr int EL_W3V = EL_W3K + 4 * 256;  // 16 frags [fo][m]: value layer 3, B-operand orientation
+constexpr int EL_B2 = EL_W3V + 16 * 256;  // 128
+constexpr int EL_BK = EL_B2 + 128;        // 16
+constexpr int EL_B3V = EL_BK + 16;        // 64
+constexpr int EL_WD = EL_B3V + 64;        // 128  (column 0 of edge layer 1: the distance weight)
+constexpr int EDGE_LDS_FLOATS = EL_WD + 128;   // 11600
+
+// per-atom records written by the node kernel and read by the edge kernel (float counts)
+constexpr int REC_NB = 608;    // [fb 8][g 4][A,C0,C1,C2][r 4] = 512, then p[3][32]
+constexpr int REC_CEN = 528;   // [fb 8][kg 4: G0,G1,G2,U][f 16] = 512, then Q[12] padded to 16
+constexpr int REC_Z = 256;     // Zq[h*32+s] (64), Zp[c][h*32+s] (192)
 struct ModelW {
     MlpW em, sam, zdm, dm;
     LinearW zdm_vec;

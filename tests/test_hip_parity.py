@@ -10,6 +10,13 @@ from pesto_amd.config import CONFIGS
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["mfma", "v1"])
+def impl(request, monkeypatch):
+    """Both layer implementations: the MFMA path (default, shipped) and the LDS-tiled VALU path (PESTO_IMPL=v1)."""
+    monkeypatch.setenv("PESTO_IMPL", "v1" if request.param == "v1" else "v2")
+    return request.param
+
+
 def _model(tag):
     from pesto_amd import Model
     m = Model(CONFIGS[tag])
@@ -35,7 +42,7 @@ def test_stage_embed_unpack():
 
 
 @pytest.mark.parametrize("layer", [0, 3, 4, 8, 12, 15])
-def test_stage_layer(layer):
+def test_stage_layer(layer, impl):
     g = golden("ops_i_v4_0_crop200")
     m = _model("i_v4_0")
     m.stage_unpack(g["X"], g["ids_topk"].astype(np.int32))
@@ -59,7 +66,7 @@ def test_stage_pool_decode():
     ("i_v4_0", "fwd_i_v4_0_2CUA"), ("i_v4_0", "fwd_i_v4_0_2AYO"), ("i_v3_0", "fwd_i_v3_0_2CUA"), ("i_v3_1", "fwd_i_v3_1h_2CUA"),
     ("i_v4_0", "edge_n40"), ("i_v4_0", "edge_batch2"), ("i_v4_0", "edge_coincident"), ("i_v4_0", "edge_single_atom_residue"),
 ])
-def test_forward_golden(tag, fixture):
+def test_forward_golden(tag, fixture, impl):
     g = golden(fixture)
     m = _model(tag)
     roa = g["res_of_atom"]
