@@ -36,9 +36,9 @@ def layer_gather_bytes_per_atom(nn):
     return 1024.0 + 532.0 * nn
 
 
-def make_batch(n_atoms, batch, seed0, n0):
+def make_batch(n_atoms, batch, seed0, n0, order="random"):
     from pesto_amd.topology import collate_batch_features, mask_to_segments, synthetic_structure
-    items = [list(synthetic_structure(n_atoms, seed0 + b, n0=n0)) for b in range(batch)]
+    items = [list(synthetic_structure(n_atoms, seed0 + b, n0=n0, order=order)) for b in range(batch)]
     X, ids, q, M = collate_batch_features(items)
     roa, R = mask_to_segments(M)
     return X, ids, q, roa, R
@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--config", default="i_v4_1")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency side measurement")
+    ap.add_argument("--order", default="random", choices=["random", "morton"],
+                    help="atom numbering of the synthetic clouds: generation order, or along a Z-order curve")
     args = ap.parse_args()
 
     import torch
@@ -119,7 +121,7 @@ def main():
     model.load_state_dict(sd)
 
     # ---- inputs: one batch per rank, resident in HBM before the timed region
-    X, ids, q, roa, R = make_batch(args.atoms, args.batch, 1000 * rank + 1, n0)
+    X, ids, q, roa, R = make_batch(args.atoms, args.batch, 1000 * rank + 1, n0, args.order)
     Xd = torch.from_numpy(X).to(dev)
     idsd = torch.from_numpy(ids).to(dev)            # int64, as the reference passes it
     qd = torch.from_numpy(q).to(dev)
@@ -168,7 +170,7 @@ def main():
     # ---- side measurement: batch-1 latency (ms per structure when structures arrive one at a time)
     lat_ms = None
     if not args.no_latency and args.batch > 1:
-        X1, ids1, q1, roa1, R1 = make_batch(args.atoms, 1, 1000 * rank + 1, n0)
+        X1, ids1, q1, roa1, R1 = make_batch(args.atoms, 1, 1000 * rank + 1, n0, args.order)
         a = [torch.from_numpy(v).to(dev) for v in (X1, ids1, q1, roa1)]
         for _ in range(3):
             model.forward_segments(a[0], a[1], a[2], a[3], R1)
@@ -199,7 +201,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config} forward ({len(config['sum'])} state-update layers), synthetic cloud "
                                    f"N={args.atoms} atoms k=64 R={R // args.batch} per structure, {args.batch} structures "
-                                   f"collated per step per GPU, inputs resident in HBM, {wdesc}",
+                                   f"collated per step per GPU, atom order {args.order}, inputs resident in HBM, {wdesc}",
                        "atoms_per_step_per_gpu": int(n_atoms_total), "structures_per_step_per_gpu": args.batch,
                        "sharding": f"{world} rank(s), independent structures per rank, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "state-update layer kernels (all launches of one forward)",

@@ -9,7 +9,7 @@ import os
 from .config import MAX_LAYERS, normalise
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpesto_hip.so")
+LIB_PATH = os.environ.get("PESTO_LIB") or os.path.join(_HERE, "csrc", "libpesto_hip.so")   # PESTO_LIB: developer builds
 
 PTR_HOST, PTR_DEVICE = 0, 1
 IDS_INT32, IDS_INT64 = 32, 64

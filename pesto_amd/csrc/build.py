@@ -14,6 +14,12 @@ SOURCES = ["pesto_schema.cpp", "pesto_kernels.hip", "pesto_layer_mfma.hip", "pes
 HEADERS = ["pesto_schema.h", "pesto_kernels.h", os.path.join("..", "..", "include", "pesto_hip.h")]
 OUT = os.path.join(HERE, "libpesto_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# developer variants: PESTO_EXTRA_CXXFLAGS="-DPESTO_PROFILE_PHASES" PESTO_LIB_TAG=prof -> libpesto_hip_prof.so (selected at
+# run time with PESTO_LIB=<path>); the default build is what ships
+EXTRA = os.environ.get("PESTO_EXTRA_CXXFLAGS", "").split()
+TAG = os.environ.get("PESTO_LIB_TAG", "")
+if TAG:
+    OUT = os.path.join(HERE, f"libpesto_hip_{TAG}.so")
 
 
 def hipcc():
@@ -33,7 +39,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
     jobs = []
@@ -41,7 +47,7 @@ def build(force=False, verbose=True):
         src = os.path.join(HERE, s)
         obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
         if force or _stale(obj, [src] + hdrs):
-            cmd = [cc] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
+            cmd = [cc] + FLAGS + EXTRA + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):

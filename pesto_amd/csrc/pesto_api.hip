@@ -201,7 +201,9 @@ int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weight
 int pesto_destroy(pesto_model* m) {
     if (!m) return 0;
     hipSetDevice(m->device);
-    if (m->stream) { hipStreamSynchronize(m->stream); hipStreamDestroy(m->stream); }
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    (void)hipDeviceSynchronize();
+    debug_print_phase_cycles();
     for (auto& e : m->ev) if (e) hipEventDestroy(e);
     if (m->W) hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,

@@ -54,22 +54,30 @@ template <typename IdT>
 __global__ __launch_bounds__(256) void k_unpack1(int N, int k, const float* __restrict__ X, const IdT* __restrict__ ids,
                                                  int* __restrict__ ids_s, float4* __restrict__ geo,
                                                  unsigned* __restrict__ dmax_bits, int* __restrict__ err_flag) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over N * 64 slots
     float d = 0.0f;
-    if (e < (int64_t)N * KMAX) {
+    // 4 slots per thread (grid-stride by the grid size) keeps the number of blocks, hence atomics, at a quarter
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)N * KMAX; e += (int64_t)gridDim.x * 256) {
         const int i = (int)(e >> 6), c = (int)(e & 63);
         long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
         if (id < 0 || id > N) { atomicOr(err_flag, 1); id = 0; }
         long long j = id - 1;
         if (j < 0) j += N;
         const float rx = X[3 * j] - X[3 * i], ry = X[3 * j + 1] - X[3 * i + 1], rz = X[3 * j + 2] - X[3 * i + 2];
-        d = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float dd = sqrtf(rx * rx + ry * ry + rz * rz);
+        d = fmaxf(d, dd);
         ids_s[(size_t)(i + 1) * KMAX + c] = (int)id;
-        geo[(size_t)(i + 1) * KMAX + c] = make_float4(rx, ry, rz, d);
+        geo[(size_t)(i + 1) * KMAX + c] = make_float4(rx, ry, rz, dd);
     }
-    // wave max, then one atomic per wave
+    // wave max -> block max -> ONE atomic per block (a single word saturates at ~90 atomics/us: one per wave
+    // cost 277 us at 24k atoms)
+    __shared__ float wmax[4];
     for (int off = 32; off > 0; off >>= 1) d = fmaxf(d, __shfl_xor(d, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(dmax_bits, __float_as_uint(d));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.0f) atomicMax(dmax_bits, __float_as_uint(m));
+    }
 }
 
 // pass 2: D += max(D) * (D < 1e-2);  R /= D.  Also writes the sink row 0.   src/model_operations.py:12-20
@@ -482,7 +490,7 @@ void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int n0,
 void launch_unpack(hipStream_t st, int N, int k, const float* X, const void* ids, int ids_kind, int* ids_s, float4* geo,
                    unsigned* dmax_bits, int* err_flag) {
     const int64_t n1 = (int64_t)N * KMAX;
-    const dim3 grid1((unsigned)((n1 + 255) / 256)), grid2((unsigned)((n1 + KMAX + 255) / 256));
+    const dim3 grid1((unsigned)((n1 + 1023) / 1024)), grid2((unsigned)((n1 + KMAX + 255) / 256));
     if (ids_kind == PESTO_IDS_INT64)
         hipLaunchKernelGGL(k_unpack1<long long>, grid1, dim3(256), 0, st, N, k, X, (const long long*)ids, ids_s, geo, dmax_bits, err_flag);
     else

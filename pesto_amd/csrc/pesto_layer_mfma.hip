@@ -20,6 +20,8 @@
 // 16fb + 4g + r from lane group g; weight fragments are stored to match: lane (o, kg) holds W[o][16fb + 4kg + r].
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "pesto_kernels.h"
 
 namespace pesto {
@@ -51,8 +53,12 @@ __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, Layer
                                               int N1, float* __restrict__ q_state, float* __restrict__ p_state,
                                               const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen) {
     const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile * 16 >= N1) return;
+    // same XCD-aware atom partition as the edge kernel: XCD b % 8 owns a contiguous eighth of the 16-atom tiles,
+    // so the records it writes are the ones its own L2 will be asked for by the edge kernel's centre reads
+    const int n_tiles = (N1 + 15) >> 4, chunk = (n_tiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile = xcd * chunk + jb * 4 + (threadIdx.x >> 6);
+    if (tile >= min(n_tiles, (xcd + 1) * chunk)) return;
     const int i_raw = tile * 16 + e;
     const bool valid = i_raw < N1;
     const int i = valid ? i_raw : N1 - 1;
@@ -186,32 +192,76 @@ __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, Layer
 }
 
 // =============================================================================================== edge kernel
+#ifdef PESTO_PROFILE_PHASES   // developer build: per-phase wave cycles (s_memtime), printed by pesto_destroy
+__device__ unsigned long long g_phase_cycles[8];
+#define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); phase_acc_[k] += now_ - tmark_; tmark_ = now_; } while (0)
+#define PHASE_INIT() tmark_ = __builtin_readcyclecounter()
+#define PHASE_DECL() unsigned long long tmark_ = 0, phase_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_phase_cycles[k_], phase_acc_[k_]); } while (0)
+#else
+#define PHASE_MARK(k) do {} while (0)
+#define PHASE_INIT() do {} while (0)
+#define PHASE_DECL() do {} while (0)
+#define PHASE_FLUSH() do {} while (0)
+#endif
 struct EdgeWaveScratch {
     int nb[64];          // neighbour id per row
     float geo[4][64];    // r_hat x, y, z and d per row (SoA)
     float wts[8][64];    // attention weights [h*4 + part][row]: part 0 scalar, 1..3 the vector chunks
     float wsum[8][2];    // per centre: sum over edges of the part-2 weights (multiplies p_i)
     float zbuf[2][256];  // Zq | Zp staging per centre (two centres per tile when NN == 8)
+    float z3buf[2][2][96];  // [centre sel][h][c*32+s]: sum_e w3[h][e] p_j(e), staged for the final combine
 };
 struct EdgeSmem {
     float w[EDGE_LDS_FLOATS];
     EdgeWaveScratch ws[4];
 };
 
-// first edge layer for feature block fb of one 16-edge tile: h1[r] = ELU(pre-activation of feature 16fb+4g+r, edge e)
+// Operands of the first edge layer for feature block fb of one 16-edge tile, fetched one or two blocks AHEAD of
+// their use (explicit software prefetch: with 2 waves per SIMD the gather latency is not hidden otherwise).
+struct L1Ops { f32x4 a4, c0, c1, c2; float cenA, cenB; };
+
 template <int NN>
-__device__ __forceinline__ f32x4 edge_l1(int fb, int lane, int g, const float* __restrict__ cenA, const float* __restrict__ cenB,
-                                         float bgA, float bgB, const float* __restrict__ recj, const float* __restrict__ wd,
-                                         float d, float rx, float ry, float rz) {
-    f32x4 acc = MFMA(cenA[fb * 64 + lane], bgA, (f32x4{0, 0, 0, 0}));          // sum_c G_i[c] r_c + U_i, centre A columns
-    if (NN == 8) acc = MFMA(cenB[fb * 64 + lane], bgB, acc);                   // second centre of the tile
+__device__ __forceinline__ L1Ops l1_fetch(int fb, int lane, int g, const float* __restrict__ cenA, const float* __restrict__ cenB,
+                                          const float* __restrict__ recj) {
+    L1Ops o;
     const float* rp = recj + (fb * 4 + g) * 16;
-    const f32x4 a4 = ld4(rp), c0 = ld4(rp + 4), c1 = ld4(rp + 8), c2 = ld4(rp + 12);
+    o.a4 = ld4(rp); o.c0 = ld4(rp + 4); o.c1 = ld4(rp + 8); o.c2 = ld4(rp + 12);
+    o.cenA = cenA[fb * 64 + lane];
+    o.cenB = NN == 8 ? cenB[fb * 64 + lane] : 0.0f;
+    return o;
+}
+
+// h1[r] = ELU(pre-activation of feature 16fb+4g+r, edge e)
+template <int NN>
+__device__ __forceinline__ f32x4 l1_compute(const L1Ops& o, int fb, int g, float bgA, float bgB, const float* __restrict__ wd,
+                                            float d, float rx, float ry, float rz) {
+    f32x4 acc = MFMA(o.cenA, bgA, (f32x4{0, 0, 0, 0}));          // sum_c G_i[c] r_c + U_i, centre A columns
+    if (NN == 8) acc = MFMA(o.cenB, bgB, acc);                   // second centre of the tile
     const f32x4 w4 = ld4(wd + 16 * fb + 4 * g);
     f32x4 h;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h[r] = elu_f(acc[r] + a4[r] + d * w4[r] + rx * c0[r] + ry * c1[r] + rz * c2[r]);
+    for (int r = 0; r < 4; ++r) h[r] = elu_f(acc[r] + o.a4[r] + d * w4[r] + rx * o.c0[r] + ry * o.c1[r] + rz * o.c2[r]);
     return h;
+}
+
+// per-tile addressing: centre record(s), neighbour record of this lane's edge, geometry
+struct TileCtx { const float *cenA, *cenB, *recj; float rx, ry, rz, d, bgA, bgB; };
+
+template <int NN>
+__device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1, const EdgeWaveScratch& ws,
+                                            const float* __restrict__ rec_nb, const float* __restrict__ rec_cen) {
+    TileCtx c;
+    const int row = 16 * t + e;
+    const int aA = NN == 8 ? 2 * t : (16 * t) / NN;
+    c.cenA = rec_cen + (size_t)min(c0 + aA, N1 - 1) * REC_CEN;
+    c.cenB = rec_cen + (size_t)min(c0 + aA + 1, N1 - 1) * REC_CEN;
+    c.rx = ws.geo[0][row]; c.ry = ws.geo[1][row]; c.rz = ws.geo[2][row]; c.d = ws.geo[3][row];
+    const float bg = g == 0 ? c.rx : (g == 1 ? c.ry : (g == 2 ? c.rz : 1.0f));
+    c.bgA = (NN == 8 && e >= 8) ? 0.0f : bg;
+    c.bgB = (NN == 8 && e >= 8) ? bg : 0.0f;
+    c.recj = rec_nb + (size_t)ws.nb[row] * REC_NB;
+    return c;
 }
 
 template <int NN>
@@ -236,8 +286,16 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
     const float* w3v = sm.w + EL_W3V;
     const float sdk = sqrtf((float)NK);
 
-    for (int work = blockIdx.x * 4 + wave; work < n_work; work += gridDim.x * 4) {
+    // XCD-aware work mapping: workgroup b runs on XCD b % 8 (observed dispatch order; speed only). Each XCD owns
+    // one contiguous eighth of the work items, consecutive workgroups of an XCD take consecutive items, so the
+    // neighbour records a CU gathers are mostly ones its own XCD's L2 already holds.
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    const int chunk = (n_work + 7) >> 3;
+    const int w_end = min(n_work, (xcd + 1) * chunk);
+    PHASE_DECL();
+    for (int work = xcd * chunk + jb * 4 + wave; work < w_end; work += nbx * 4) {
         const int c0 = work * A;
+        PHASE_INIT();
         {   // rows of this work item: lane = row
             const int a = lane / NN, c = lane % NN, i = c0 + a;
             const bool valid = i < N1;
@@ -246,43 +304,55 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
             ws.geo[0][lane] = gg.x; ws.geo[1][lane] = gg.y; ws.geo[2][lane] = gg.z; ws.geo[3][lane] = gg.w;
         }
         __builtin_amdgcn_wave_barrier();
+        PHASE_MARK(0);
 
         // ------------------------------------------------------------------ pass 1: keys -> logits (eqkm, epkm)
         float lg[4][2];
+        {
+            // tile-batched: the four first-layer blocks of a tile are computed together (VALU phase, independent
+            // chains), then the layer-2/3 MFMA chains run dense; the NEXT tile's gathers are issued in between
+            TileCtx tc[2];
+            tc[0] = tile_ctx<NN>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
+            L1Ops ops[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int row = 16 * t + e;
-            const int aA = NN == 8 ? 2 * t : (16 * t) / NN;            // centre(s) of this tile (local index)
-            const int iA = min(c0 + aA, N1 - 1), iB = min(c0 + aA + 1, N1 - 1);
-            const int aMine = NN == 8 ? aA + (e >> 3) : aA;
-            const int iMine = min(c0 + aMine, N1 - 1);
-            const float* cenA = rec_cen + (size_t)iA * REC_CEN;
-            const float* cenB = rec_cen + (size_t)iB * REC_CEN;
-            const float rx = ws.geo[0][row], ry = ws.geo[1][row], rz = ws.geo[2][row], d = ws.geo[3][row];
-            const float bg = g == 0 ? rx : (g == 1 ? ry : (g == 2 ? rz : 1.0f));
-            const float bgA = (NN == 8 && e >= 8) ? 0.0f : bg, bgB = (NN == 8 && e >= 8) ? bg : 0.0f;
-            const float* recj = rec_nb + (size_t)ws.nb[row] * REC_NB;
-            f32x4 acc2[4];
+            for (int fb = 0; fb < 4; ++fb) ops[0][fb] = l1_fetch<NN>(fb, lane, g, tc[0].cenA, tc[0].cenB, tc[0].recj);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc2[m] = ld4(sm.w + EL_B2 + 16 * m + 4 * g);
+            for (int t = 0; t < 4; ++t) {
+                const TileCtx& tcc = tc[t & 1];
+                f32x4 h1[4];
 #pragma unroll
-            for (int fb = 0; fb < 4; ++fb) {
-                const f32x4 h1 = edge_l1<NN>(fb, lane, g, cenA, cenB, bgA, bgB, recj, sm.w + EL_WD, d, rx, ry, rz);
-                const int net = fb >> 1, fbl = fb & 1;
+                for (int fb = 0; fb < 4; ++fb)
+                    h1[fb] = l1_compute<NN>(ops[t & 1][fb], fb, g, tcc.bgA, tcc.bgB, sm.w + EL_WD, tcc.d, tcc.rx, tcc.ry, tcc.rz);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t < 3) {
+                    tc[(t + 1) & 1] = tile_ctx<NN>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
+                    const TileCtx& tn = tc[(t + 1) & 1];
 #pragma unroll
-                for (int ml = 0; ml < 2; ++ml)
-                    acc2[net * 2 + ml] = mfma_block<2>(w2f + net * 4 * 256, ml, fbl, lane, h1, acc2[net * 2 + ml]);
+                    for (int fb = 0; fb < 4; ++fb) ops[(t + 1) & 1][fb] = l1_fetch<NN>(fb, lane, g, tn.cenA, tn.cenB, tn.recj);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc2[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc2[m] = ld4(sm.w + EL_B2 + 16 * m + 4 * g);
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb) {
+                    const int net = fb >> 1, fbl = fb & 1;
+#pragma unroll
+                    for (int ml = 0; ml < 2; ++ml)
+                        acc2[net * 2 + ml] = mfma_block<2>(w2f + net * 4 * 256, ml, fbl, lane, h1[fb], acc2[net * 2 + ml]);
+                }
+                f32x4 kacc = ld4(sm.w + EL_BK + 4 * g);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) kacc = mfma_block<4>(w3k, 0, m, lane, elu4(acc2[m]), kacc);
+                // lane (e, g): kacc[0..2] = key of part g for edge row; logits against Q[0] (scalar) or Q[1] (vector)
+                const int aMine = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
+                const float* Qv = rec_cen + (size_t)min(c0 + aMine, N1 - 1) * REC_CEN + 512 + (g == 0 ? 0 : 6);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    lg[t][h] = (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) / sdk;
             }
-            f32x4 kacc = ld4(sm.w + EL_BK + 4 * g);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) kacc = mfma_block<4>(w3k, 0, m, lane, elu4(acc2[m]), kacc);
-            // lane (e, g): kacc[0..2] = key of part g for edge row; logits against Q[0] (scalar) or Q[1] (vector)
-            const float* Qv = rec_cen + (size_t)iMine * REC_CEN + 512 + (g == 0 ? 0 : 6);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                lg[t][h] = (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) / sdk;
         }
-
+        PHASE_MARK(1);
         // ------------------------------------------------------------------ softmax per centre  (:139-140)
         // scalar: over the NN rows of part 0; vector: over the 3*NN slots of parts 1..3 together
 #pragma unroll
@@ -320,33 +390,61 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
             }
         }
         __builtin_amdgcn_wave_barrier();
+        PHASE_MARK(2);
 
         // ------------------------------------------------------------------ pass 2: values (evm) and the weighted sums
-        float zq[2][2], zp1[2][3][2], zp3[2][2];
+        float zq[2][2], zp1[2][3][2];
+        f32x4 z3a[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, z3b[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) { zq[h][k] = 0.f; zp3[h][k] = 0.f; zp1[h][0][k] = zp1[h][1][k] = zp1[h][2][k] = 0.f; }
+            for (int k = 0; k < 2; ++k) { zq[h][k] = 0.f; zp1[h][0][k] = zp1[h][1][k] = zp1[h][2][k] = 0.f; }
 
+        TileCtx tcn = tile_ctx<NN>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
+        L1Ops pre[4];
+#pragma unroll
+        for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
         for (int t = 0; t < 4; ++t) {
-            const int row = 16 * t + e;
-            const int aA = NN == 8 ? 2 * t : (16 * t) / NN;
-            const int iA = min(c0 + aA, N1 - 1), iB = min(c0 + aA + 1, N1 - 1);
-            const float* cenA = rec_cen + (size_t)iA * REC_CEN;
-            const float* cenB = rec_cen + (size_t)iB * REC_CEN;
-            const float rx = ws.geo[0][row], ry = ws.geo[1][row], rz = ws.geo[2][row], d = ws.geo[3][row];
-            const float bg = g == 0 ? rx : (g == 1 ? ry : (g == 2 ? rz : 1.0f));
-            const float bgA = (NN == 8 && e >= 8) ? 0.0f : bg, bgB = (NN == 8 && e >= 8) ? bg : 0.0f;
-            const float* recj = rec_nb + (size_t)ws.nb[row] * REC_NB;
+            const TileCtx tc = tcn;
+            // neighbours' p_j of this tile (third block of Vp, :134) as 16-byte gathers: lane = (esub = lane / 24, quad =
+            // lane % 24) reads floats 4*quad..+3 of the 96-vector of edges 2i + esub; issued first, consumed after the
+            // first-layer VALU work below
+            const int esub = lane / 24, quad = lane - 24 * esub;
+            f32x4 pv[8];
+#pragma unroll
+            for (int i2 = 0; i2 < 8; ++i2) {
+                const int ee = 2 * i2 + (esub & 1);
+                const float* pj = rec_nb + (size_t)ws.nb[16 * t + ee] * REC_NB + 512 + 4 * quad;
+                pv[i2] = esub < 2 ? ld4(pj) : f32x4{0, 0, 0, 0};
+            }
+            f32x4 h1[4];
+#pragma unroll
+            for (int fbl = 0; fbl < 4; ++fbl)
+                h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i2 = 0; i2 < 8; ++i2) {
+                const int ee = 2 * i2 + (esub & 1);
+                const float w0 = ws.wts[3][16 * t + ee], w1 = ws.wts[7][16 * t + ee];
+                if (NN == 8 && i2 >= 4) { z3b[0] += w0 * pv[i2]; z3b[1] += w1 * pv[i2]; }
+                else { z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the first-layer operands of the NEXT tile fly during this tile's MFMA phase
+            if (t < 3) {
+                tcn = tile_ctx<NN>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
+#pragma unroll
+                for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 acc2[4];
 #pragma unroll
             for (int ml = 0; ml < 4; ++ml) acc2[ml] = ld4(sm.w + EL_B2 + 64 + 16 * ml + 4 * g);
 #pragma unroll
-            for (int fbl = 0; fbl < 4; ++fbl) {
-                const f32x4 h1 = edge_l1<NN>(4 + fbl, lane, g, cenA, cenB, bgA, bgB, recj, sm.w + EL_WD, d, rx, ry, rz);
+            for (int fbl = 0; fbl < 4; ++fbl)
 #pragma unroll
-                for (int ml = 0; ml < 4; ++ml) acc2[ml] = mfma_block<4>(w2f + 8 * 256, ml, fbl, lane, h1, acc2[ml]);
-            }
+                for (int ml = 0; ml < 4; ++ml) acc2[ml] = mfma_block<4>(w2f + 8 * 256, ml, fbl, lane, h1[fbl], acc2[ml]);
+            PHASE_MARK(3);
             f32x4 h2[4];
 #pragma unroll
             for (int ml = 0; ml < 4; ++ml) h2[ml] = elu4(acc2[ml]);
@@ -365,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
                     v[fo] = MFMA(h2[ml][3], wv[3], v[fo]);
                 }
             }
+            PHASE_MARK(4);
             // attention-weighted sums over this lane's four edges (:143-144, first block of Vp :132)
             const int r0 = 16 * t + 4 * g;
             const f32x4 gx = ld4(&ws.geo[0][r0]), gy = ld4(&ws.geo[1][r0]), gz = ld4(&ws.geo[2][r0]);
@@ -381,17 +480,8 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
                     zp1[h][2][0] += wz * v[2][r]; zp1[h][2][1] += wz * v[3][r];
                 }
             }
-            if ((t + 1) % TPC != 0) {   // centre continues in the next tile: only the p_j gather for this tile
-#pragma unroll 4
-                for (int ee = 0; ee < 16; ++ee) {
-                    const int rr = 16 * t + ee;
-                    const float* pj = rec_nb + (size_t)ws.nb[rr] * REC_NB + 512;
-                    const float p0 = pj[lane], p1 = lane < 32 ? pj[64 + lane] : 0.0f;
-                    const float w0 = ws.wts[3][rr], w1 = ws.wts[7][rr];
-                    zp3[0][0] += w0 * p0; zp3[0][1] += w0 * p1; zp3[1][0] += w1 * p0; zp3[1][1] += w1 * p1;
-                }
-                continue;
-            }
+            PHASE_MARK(5);
+            if ((t + 1) % TPC != 0) continue;   // centre continues in the next tile
             // ---- centre(s) complete: reduce the per-lane partial sums across lane groups, stage in LDS
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -407,6 +497,22 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
                         zp1[h][c][k] = y;
                     }
                 }
+            {   // p_j sums: fold the two edge-parity lane groups, stage [h][96] per centre
+                const int esub2 = lane / 24, quad2 = lane - 24 * esub2;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        z3a[h][j] += __shfl_down(z3a[h][j], 24);
+                        if (NN == 8) z3b[h][j] += __shfl_down(z3b[h][j], 24);
+                    }
+                    if (esub2 == 0) {
+                        st4(&ws.z3buf[0][h][4 * quad2], z3a[h]);
+                        if (NN == 8) st4(&ws.z3buf[1][h][4 * quad2], z3b[h]);
+                    }
+                    z3a[h] = f32x4{0, 0, 0, 0}; z3b[h] = f32x4{0, 0, 0, 0};
+                }
+            }
             if (g == 0 || (NN == 8 && g == 2)) {
                 float* zb = ws.zbuf[(NN == 8 && g == 2) ? 1 : 0];
 #pragma unroll
@@ -423,14 +529,6 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
             for (int sel = 0; sel < (NN == 8 ? 2 : 1); ++sel) {
                 const int a = NN == 8 ? 2 * t + sel : (16 * t) / NN;
                 const int i = c0 + a;
-                const int e0 = NN == 8 ? 8 * sel : 0, e1 = NN == 8 ? 8 * sel + 8 : 16;
-                for (int ee = e0; ee < e1; ++ee) {                      // third block of Vp: neighbours' p_j  (:134)
-                    const int rr = 16 * t + ee;
-                    const float* pj = rec_nb + (size_t)ws.nb[rr] * REC_NB + 512;
-                    const float p0 = pj[lane], p1 = lane < 32 ? pj[64 + lane] : 0.0f;
-                    const float w0 = ws.wts[3][rr], w1 = ws.wts[7][rr];
-                    zp3[0][0] += w0 * p0; zp3[0][1] += w0 * p1; zp3[1][0] += w1 * p0; zp3[1][1] += w1 * p1;
-                }
                 if (i < N1) {
                     const float* zb = ws.zbuf[sel];
                     const float* pi = rec_nb + (size_t)i * REC_NB + 512;       // second block of Vp: p_i  (:133)
@@ -440,32 +538,44 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
                     const float pi0 = pi[lane];
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
-                        zo[64 + c * 64 + h * 32 + s] = zb[64 + c * 64 + h * 32 + s] + ws.wsum[a][h] * pi0 + zp3[h][0];
+                        zo[64 + c * 64 + h * 32 + s] = zb[64 + c * 64 + h * 32 + s] + ws.wsum[a][h] * pi0 + ws.z3buf[sel][h][lane];
                     if (lane < 32) {
                         const float pi1 = pi[64 + lane];
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
-                            zo[64 + 128 + h * 32 + lane] = zb[64 + 128 + h * 32 + lane] + ws.wsum[a][h] * pi1 + zp3[h][1];
+                            zo[64 + 128 + h * 32 + lane] = zb[64 + 128 + h * 32 + lane] + ws.wsum[a][h] * pi1 + ws.z3buf[sel][h][64 + lane];
                     }
                 }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) { zp3[h][0] = 0.f; zp3[h][1] = 0.f; }
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) { zq[h][k] = 0.f; zp1[h][0][k] = zp1[h][1][k] = zp1[h][2][k] = 0.f; }
             __builtin_amdgcn_wave_barrier();
+            PHASE_MARK(6);
         }
     }
+    PHASE_FLUSH();
+}
+
+void debug_print_phase_cycles() {
+#ifdef PESTO_PROFILE_PHASES
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_cycles), sizeof h) == hipSuccess) {
+        const char* names[8] = {"setup", "pass1(keys)", "softmax", "p2:L1+L2", "p2:L3(values)", "p2:accumulate", "p2:finalize", "-"};
+        double tot = 0;
+        for (int k = 0; k < 7; ++k) tot += (double)h[k];
+        for (int k = 0; k < 7; ++k) fprintf(stderr, "[pesto phase] %-16s %6.2f %%  (%llu)\n", names[k], 100.0 * h[k] / tot, h[k]);
+    }
+#endif
 }
 
 // =============================================================================================== launchers
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
                  const float* Z, float* rec_nb, float* rec_cen) {
-    const int tiles = (N1 + 15) / 16;
+    const int tiles = (N1 + 15) / 16, chunk = (tiles + 7) / 8;
     const LayerW dummy{};
-    hipLaunchKernelGGL(k_node, dim3((tiles + 3) / 4), dim3(256), 0, st, W, finish ? *finish : dummy, prep ? *prep : dummy,
+    hipLaunchKernelGGL(k_node, dim3((chunk + 3) / 4 * 8), dim3(256), 0, st, W, finish ? *finish : dummy, prep ? *prep : dummy,
                        finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
 }
 
@@ -473,8 +583,9 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
                  const float* rec_nb, const float* rec_cen, float* Z, int max_blocks) {
     const int A = 64 / lw.nn;
     const int n_work = (N1 + A - 1) / A;
-    int blocks = (n_work + 3) / 4;
-    if (blocks > max_blocks) blocks = max_blocks;
+    int blocks = ((n_work + 7) / 8 + 3) / 4 * 8;      // per-XCD share of the work items, 4 per workgroup, x 8 XCDs
+    if (blocks > max_blocks) blocks = max_blocks / 8 * 8;
+    if (blocks < 8) blocks = 8;
     const dim3 grid(blocks), block(256);
     switch (lw.nn) {
         case 8: hipLaunchKernelGGL(k_edge<8>, grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;

@@ -167,10 +167,29 @@ def synthetic_cloud(n, seed=1, density=0.05, min_sep=0.5):
     return pts.astype(np.float32)
 
 
-def synthetic_structure(n, seed=1, n0=30, atoms_per_res=8, k=64):
+def morton_order(X, bits=10):
+    """Permutation sorting points along a Z-order (Morton) curve: consecutive atoms become spatial neighbours,
+    as consecutive atoms of a real chain are."""
+    Xn = np.asarray(X, dtype=np.float64)
+    lo, hi = Xn.min(0), Xn.max(0)
+    cells = np.minimum(((Xn - lo) / np.maximum(hi - lo, 1e-9) * (1 << bits)).astype(np.int64), (1 << bits) - 1)
+    code = np.zeros(Xn.shape[0], dtype=np.int64)
+    for b in range(bits):
+        for c in range(3):
+            code |= ((cells[:, c] >> b) & 1) << (3 * b + c)
+    return np.argsort(code, kind="stable")
+
+
+def synthetic_structure(n, seed=1, n0=30, atoms_per_res=8, k=64, order="random"):
     """One synthetic structure with the reference's per-structure contract (before collation):
-    X float32 [n,3]; ids_topk int64 [n, min(k,n)] 0-based; q float32 one-hot [n, n0]; M bool [n, R]."""
+    X float32 [n,3]; ids_topk int64 [n, min(k,n)] 0-based; q float32 one-hot [n, n0]; M bool [n, R].
+    order="random": atoms in generation order (no spatial locality; what the golden fixtures use);
+    order="morton": the same cloud with atoms renumbered along a Z-order curve (chain-like locality)."""
     X = synthetic_cloud(n, seed)
+    if order == "morton":
+        X = np.ascontiguousarray(X[morton_order(X)])
+    elif order != "random":
+        raise ValueError("order must be 'random' or 'morton'")
     rng = np.random.default_rng(seed + 7919)
     el = rng.choice(30, size=n, p=ELEMENT_P)
     q = np.zeros((n, n0), dtype=np.float32)

@@ -1,0 +1,42 @@
+#!/bin/bash
+# PMC collection for the bench workload: separate rocprofv3 --pmc passes (no tracing combined), per
+# /opt/skills/guides/MI355X_MICROARCH.md (SQ 8 slots, TCC 4 slots; FETCH_SIZE costs 3, WRITE_SIZE 2).
+# usage: profiles/pmc_collect.sh <tag>   (run on the GPU box from the repo root; writes gpurun_out/pmc_<tag>/)
+set -u
+TAG=${1:-run}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+cd /tmp
+CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-latency"
+i=0
+for SET in \
+  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
+  "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \
+  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
+  "FETCH_SIZE" \
+  "WRITE_SIZE GRBM_GUI_ACTIVE"
+do
+  i=$((i+1))
+  rocprofv3 --pmc $SET -d $R/gpurun_out/pmc_$TAG/p$i -o pmc --output-format csv -- $CMD > $R/gpurun_out/pmc_$TAG/p$i.log 2>&1 || echo "pass $i failed"
+done
+python - "$R/gpurun_out/pmc_$TAG" <<'PY'
+import csv, glob, sys, collections
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(int)
+for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0][-40:]
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        if row["Counter_Name"] in ("SQ_WAVE_CYCLES", "SQ_INSTS_LDS", "TCC_HIT_sum", "FETCH_SIZE", "WRITE_SIZE"):
+            cnt[(k, row["Counter_Name"])] += 1
+with open(root + "/summary.txt", "w") as out:
+    for k in sorted(agg):
+        if "k_edge" not in k and "k_node" not in k and "k_layer" not in k:
+            continue
+        n = max([v for (kk, c), v in cnt.items() if kk == k] + [1])
+        out.write(f"{k}  dispatches~{n}\n")
+        for c in sorted(agg[k]):
+            out.write(f"    {c:28s} {agg[k][c] / n:16.1f} per dispatch\n")
+print(open(root + "/summary.txt").read())
+PY
