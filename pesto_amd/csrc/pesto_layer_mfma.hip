@@ -410,11 +410,10 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
             // lane % 24) reads floats 4*quad..+3 of the 96-vector of edges 2i + esub; issued first, consumed after the
             // first-layer VALU work below
             const int esub = lane / 24, quad = lane - 24 * esub;
-            f32x4 pv[8];
+            f32x4 pv[4];
 #pragma unroll
-            for (int i2 = 0; i2 < 8; ++i2) {
-                const int ee = 2 * i2 + (esub & 1);
-                const float* pj = rec_nb + (size_t)ws.nb[16 * t + ee] * REC_NB + 512 + 4 * quad;
+            for (int i2 = 0; i2 < 4; ++i2) {
+                const float* pj = rec_nb + (size_t)ws.nb[16 * t + 2 * i2 + (esub & 1)] * REC_NB + 512 + 4 * quad;
                 pv[i2] = esub < 2 ? ld4(pj) : f32x4{0, 0, 0, 0};
             }
             f32x4 h1[4];
@@ -423,18 +422,16 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
                 h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i2 = 0; i2 < 8; ++i2) {
+            for (int i2 = 0; i2 < 4; ++i2) {
                 const int ee = 2 * i2 + (esub & 1);
                 const float w0 = ws.wts[3][16 * t + ee], w1 = ws.wts[7][16 * t + ee];
-                if (NN == 8 && i2 >= 4) { z3b[0] += w0 * pv[i2]; z3b[1] += w1 * pv[i2]; }
-                else { z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2]; }
+                z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2];
             }
-            __builtin_amdgcn_sched_barrier(0);
             // the first-layer operands of the NEXT tile fly during this tile's MFMA phase
             if (t < 3) {
                 tcn = tile_ctx<NN>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
 #pragma unroll
-                for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
+                for (int fbl = 0; fbl < 2; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
             }
             __builtin_amdgcn_sched_barrier(0);
             f32x4 acc2[4];
@@ -445,6 +442,17 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
 #pragma unroll
                 for (int ml = 0; ml < 4; ++ml) acc2[ml] = mfma_block<4>(w2f + 8 * 256, ml, fbl, lane, h1[fbl], acc2[ml]);
             PHASE_MARK(3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {   // second half of the tile's edges: these loads land during the MFMA phase
+                const float* pj = rec_nb + (size_t)ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)] * REC_NB + 512 + 4 * quad;
+                pv[i2] = esub < 2 ? ld4(pj) : f32x4{0, 0, 0, 0};
+            }
+            if (t < 3) {   // second half of the next tile's first-layer operands: in flight during the value MFMAs
+#pragma unroll
+                for (int fbl = 2; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 h2[4];
 #pragma unroll
             for (int ml = 0; ml < 4; ++ml) h2[ml] = elu4(acc2[ml]);
@@ -464,6 +472,13 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
                 }
             }
             PHASE_MARK(4);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                const int ee = 8 + 2 * i2 + (esub & 1);
+                const float w0 = ws.wts[3][16 * t + ee], w1 = ws.wts[7][16 * t + ee];
+                if (NN == 8) { z3b[0] += w0 * pv[i2]; z3b[1] += w1 * pv[i2]; }
+                else { z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2]; }
+            }
             // attention-weighted sums over this lane's four edges (:143-144, first block of Vp :132)
             const int r0 = 16 * t + 4 * g;
             const f32x4 gx = ld4(&ws.geo[0][r0]), gy = ld4(&ws.geo[1][r0]), gz = ld4(&ws.geo[2][r0]);

@@ -1,0 +1,126 @@
+"""Structure-level sharding of a work list over the GPUs of one node.
+
+Structures never interact in the forward pass (collation only concatenates and offsets indices, reference
+src/dataset.py:102-110), so the path shards with NO data-path collective: every rank owns one MI355X, a full copy of
+the weights and its own slice of the structures.  The reference's bulk driver is a plain Python loop over
+structures (interfaceome/apply_model.py:57-82, apply_model.ipynb:139-167); this module is its multi-GPU form.
+
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests) carries only
+  * the ragged result gather: per-structure logits z_i [R_i, n_out] (a few KB each), as one all_gather of counts
+    and one all_gather of padded payloads,
+  * barriers / the max-over-ranks timing reduction of bench.py.
+"""
+import numpy as np
+
+
+def partition(costs, world_size):
+    """Longest-processing-time-first assignment of work items to ranks. ``costs[i]`` ~ atoms of structure i
+    (layer cost is O(N * nn)). Deterministic; returns a list of index lists, one per rank, each in ascending order."""
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.argsort(-costs, kind="stable")
+    load = np.zeros(world_size)
+    out = [[] for _ in range(world_size)]
+    for i in order:
+        r = int(np.argmin(load))
+        out[r].append(int(i))
+        load[r] += costs[i]
+    return [sorted(ix) for ix in out]
+
+
+def batches(indices, sizes, max_atoms):
+    """Greedy grouping of a rank's structures into collated batches of at most ``max_atoms`` atoms (>= 1 structure)."""
+    out, cur, tot = [], [], 0
+    for i in indices:
+        if cur and tot + sizes[i] > max_atoms:
+            out.append(cur)
+            cur, tot = [], 0
+        cur.append(i)
+        tot += sizes[i]
+    if cur:
+        out.append(cur)
+    return out
+
+
+def forward_local(forward_fn, structures, indices, max_atoms=32768):
+    """Run ``forward_fn(X, ids_topk, q, M) -> z`` over this rank's structures, collating several per launch.
+    ``structures[i] = (X, ids_topk0, q, M)`` with the per-structure contract of pesto_amd.topology.
+    Returns {index: z_i (numpy [R_i, n_out])}.  A structure whose batch raises is retried alone and skipped on a
+    second failure (the reference driver also skips and continues)."""
+    from .topology import collate_batch_features
+    sizes = [np.asarray(s[0]).shape[0] for s in structures]
+    results = {}
+
+    def run(group):
+        X, ids, q, M = collate_batch_features([list(structures[i]) for i in group])
+        z = forward_fn(X, ids, q, M)
+        z = z.detach().cpu().numpy() if hasattr(z, "detach") else np.asarray(z)
+        r0 = 0
+        for i in group:
+            r = np.asarray(structures[i][3]).shape[1]
+            results[i] = np.ascontiguousarray(z[r0:r0 + r])
+            r0 += r
+
+    for group in batches(indices, sizes, max_atoms):
+        try:
+            run(group)
+        except Exception:
+            for i in group:
+                try:
+                    run([i])
+                except Exception:
+                    results[i] = None
+    return results
+
+
+def gather_results(local, n_total, n_out, group=None, device="cpu"):
+    """All ranks receive every structure's z. ``local``: {index: array or None}. Two collectives:
+    all_gather of (index, rows) descriptors, all_gather of row payloads padded to the largest rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    items = sorted(local.items())
+    desc = torch.full((n_total, 2), -1, dtype=torch.int64)
+    rows = []
+    for k, (i, z) in enumerate(items):
+        desc[k, 0] = i
+        desc[k, 1] = -1 if z is None else z.shape[0]
+        if z is not None:
+            rows.append(torch.from_numpy(np.asarray(z, dtype=np.float32)).reshape(-1, n_out))
+    payload = torch.cat(rows, 0) if rows else torch.zeros((0, n_out))
+    n_rows = torch.tensor([payload.shape[0]], dtype=torch.int64)
+    desc, n_rows, payload = desc.to(device), n_rows.to(device), payload.to(device)
+    all_desc = [torch.empty_like(desc) for _ in range(world)]
+    all_rows = [torch.empty_like(n_rows) for _ in range(world)]
+    dist.all_gather(all_desc, desc, group=group)
+    dist.all_gather(all_rows, n_rows, group=group)
+    max_rows = max(int(r.item()) for r in all_rows)
+    padded = torch.zeros((max(max_rows, 1), n_out), dtype=torch.float32, device=device)
+    padded[:payload.shape[0]] = payload
+    all_pay = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(all_pay, padded, group=group)
+    out = [None] * n_total
+    for r in range(world):
+        d = all_desc[r].cpu().numpy()
+        pay = all_pay[r].cpu().numpy()
+        off = 0
+        for i, nrow in d:
+            if i < 0:
+                break
+            if nrow >= 0:
+                out[int(i)] = pay[off:off + nrow].copy()
+                off += int(nrow)
+    return out
+
+
+def forward_sharded(forward_fn, structures, n_out, max_atoms=32768, group=None, device="cpu"):
+    """Shard ``structures`` over the ranks of the (already initialised) process group, run them, gather all results
+    on every rank.  Single-process (no process group): runs everything locally."""
+    import torch.distributed as dist
+    sizes = [np.asarray(s[0]).shape[0] for s in structures]
+    if not (dist.is_available() and dist.is_initialized()):
+        local = forward_local(forward_fn, structures, list(range(len(structures))), max_atoms)
+        return [local[i] for i in range(len(structures))]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = partition(sizes, world)[rank]
+    local = forward_local(forward_fn, structures, mine, max_atoms)
+    return gather_results(local, len(structures), n_out, group=group, device=device)

@@ -1,0 +1,93 @@
+"""Multi-rank path on CPU: world_size-2 gloo process group, structures sharded by pesto_amd.sharding, forward supplied by
+the CPU oracle (the HIP forward needs a GPU; the sharding/gather logic is backend-independent). Results must equal the
+single-process results BITWISE for the same per-structure batching (SURVEY 8e acceptance)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, weights
+from pesto_amd import sharding
+from pesto_amd.config import CONFIGS
+
+
+def test_partition_is_balanced_and_complete():
+    costs = [3000, 100, 2500, 2400, 800, 799, 64, 3052, 1641]
+    parts = sharding.partition(costs, 4)
+    assert sorted(i for p in parts for i in p) == list(range(len(costs)))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= max(costs)
+    assert sharding.partition(costs, 4) == parts                      # deterministic
+    assert sharding.partition([5, 5], 4)[2:] == [[], []]              # more ranks than work
+
+
+def test_batches_respect_atom_budget():
+    sizes = [300, 200, 600, 100, 50]
+    b = sharding.batches([0, 1, 2, 3, 4], sizes, 600)
+    assert b == [[0, 1], [2], [3, 4]]
+    assert sharding.batches([2], sizes, 10) == [[2]]                  # an oversize structure still runs alone
+
+
+def _structures():
+    from pesto_amd.topology import synthetic_structure
+    return [synthetic_structure(n, seed) for n, seed in ((70, 1), (96, 2), (65, 3), (120, 4), (80, 5))]
+
+
+def _oracle_forward():
+    from oracle import oracle
+    from pesto_amd.topology import mask_to_segments
+    m = oracle.OracleModel(CONFIGS["i_v4_0"], weights("i_v4_0"))
+
+    def fwd(X, ids, q, M):
+        roa, R = mask_to_segments(M)
+        return m.forward_segments(X, np.asarray(ids).astype(np.int32), q, roa, R, stop_after=3)
+    return fwd
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        res = sharding.forward_sharded(_oracle_forward(), _structures(), n_out=5, max_atoms=200)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{str(i): z for i, z in enumerate(res)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # single-process reference with the SAME per-structure batching the ranks used
+    structures = _structures()
+    fwd = _oracle_forward()
+    sizes = [s[0].shape[0] for s in structures]
+    single = {}
+    for part in sharding.partition(sizes, 2):
+        single.update(sharding.forward_local(fwd, structures, part, max_atoms=200))
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+        assert len(got.files) == len(structures)
+        for i in range(len(structures)):
+            assert np.array_equal(got[str(i)], single[i]), (rank, i)   # bitwise
+            assert got[str(i)].shape == (structures[i][3].shape[1], 5)
+
+
+def test_failed_structure_is_skipped_not_fatal():
+    structures = _structures()[:3]
+    calls = {"n": 0}
+
+    def flaky(X, ids, q, M):
+        calls["n"] += 1
+        if np.asarray(X).shape[0] in (96, 70 + 96):      # batch containing structure 1, and structure 1 alone
+            raise RuntimeError("boom")
+        return np.zeros((np.asarray(M).shape[1], 5), np.float32)
+    res = sharding.forward_local(flaky, structures, [0, 1, 2], max_atoms=170)
+    assert res[1] is None and res[0] is not None and res[2] is not None
