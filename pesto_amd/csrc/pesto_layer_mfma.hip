@@ -45,6 +45,19 @@ __device__ __forceinline__ f32x4 mfma_block(const float* __restrict__ wf, int m,
     return acc;
 }
 
+// NM independent accumulators advanced together through the four k-steps of input block fb: consecutive MFMAs
+// never depend on each other (a 16x16x4 f32 MFMA issues every 32 cycles but its result is ready after 40)
+template <int NM, int NFB>
+__device__ __forceinline__ void mfma_multi(const float* __restrict__ wf, int m0, int fb, int lane, f32x4 x, f32x4* acc) {
+    f32x4 w[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) w[m] = ld4(wf + ((size_t)((m0 + m) * NFB + fb) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) acc[m] = MFMA(w[m][r], x[r], acc[m]);
+}
+
 // =============================================================================================== node kernel
 // finish >= 0: apply layer `finish`'s output MLPs to Z and update the state in place (sink reset).
 // prep   >= 0: write layer `prep`'s centre / neighbour records from the (updated) state.
@@ -79,37 +92,36 @@ __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, Layer
 #pragma unroll
         for (int m = 0; m < 2; ++m) h[m] = ld4(W + wf_.n_bq0 + 16 * m + 4 * g);
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
-            const f32x4 x = ld4(zr + 16 * fb + 4 * g);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) h[m] = mfma_block<4>(W + wf_.n_q0, m, fb, lane, x, h[m]);
-        }
+        for (int fb = 0; fb < 4; ++fb) mfma_multi<2, 4>(W + wf_.n_q0, 0, fb, lane, ld4(zr + 16 * fb + 4 * g), h);
 #pragma unroll
         for (int m = 0; m < 2; ++m) { h[m] = elu4(h[m]); t[m] = ld4(W + wf_.n_bq1 + 16 * m + 4 * g); }
 #pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) t[m] = mfma_block<2>(W + wf_.n_q1, m, fb, lane, h[fb], t[m]);
+        for (int fb = 0; fb < 2; ++fb) mfma_multi<2, 2>(W + wf_.n_q1, 0, fb, lane, h[fb], t);
 #pragma unroll
         for (int m = 0; m < 2; ++m) { t[m] = elu4(t[m]); h[m] = ld4(W + wf_.n_bq2 + 16 * m + 4 * g); }
 #pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) h[m] = mfma_block<2>(W + wf_.n_q2, m, fb, lane, t[fb], h[m]);
+        for (int fb = 0; fb < 2; ++fb) mfma_multi<2, 2>(W + wf_.n_q2, 0, fb, lane, t[fb], h);
 #pragma unroll
         for (int m = 0; m < 2; ++m) q[m] += h[m];                                                  // :151
         // ppm: 64 -> 32, no bias, per xyz component                                              // :148, :152
+        {
+            f32x4 a[3][2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            f32x4 a[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+            for (int c = 0; c < 3; ++c) { a[c][0] = f32x4{0, 0, 0, 0}; a[c][1] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
             for (int fb = 0; fb < 4; ++fb) {
-                const f32x4 x = ld4(zr + 64 + c * 64 + 16 * fb + 4 * g);
+                const f32x4 w0 = ld4(W + wf_.n_pp + ((size_t)(0 * 4 + fb) * 64 + lane) * 4);
+                const f32x4 w1 = ld4(W + wf_.n_pp + ((size_t)(1 * 4 + fb) * 64 + lane) * 4);
+                f32x4 x[3];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) a[m] = mfma_block<4>(W + wf_.n_pp, m, fb, lane, x, a[m]);
+                for (int c = 0; c < 3; ++c) x[c] = ld4(zr + 64 + c * 64 + 16 * fb + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { a[c][0] = MFMA(w0[r], x[c][r], a[c][0]); a[c][1] = MFMA(w1[r], x[c][r], a[c][1]); }
             }
 #pragma unroll
-            for (int m = 0; m < 2; ++m) p[c][m] += a[m];
+            for (int c = 0; c < 3; ++c) { p[c][0] += a[c][0]; p[c][1] += a[c][1]; }
         }
         if (i == 0) {                                                                              // :239-240 sink
 #pragma unroll
@@ -138,28 +150,46 @@ __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, Layer
     float* cen = rec_cen + (size_t)i * REC_CEN;
     float* nb = rec_nb + (size_t)i * REC_NB;
     // [U | A] = [W[:,1:65]; W[:,65:129]] X_n   (16 output blocks; U carries b1)
-#pragma unroll 4
-    for (int ob = 0; ob < 16; ++ob) {
-        f32x4 a = ob < 8 ? ld4(W + wp_.n_b1 + 16 * ob + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll 1
+    for (int ob = 0; ob < 16; ob += 4) {
+        f32x4 a[4];
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) a = mfma_block<4>(W + wp_.n_ua, ob, fb, lane, xn[fb], a);
+        for (int j = 0; j < 4; ++j) a[j] = ob < 8 ? ld4(W + wp_.n_b1 + 16 * (ob + j) + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) mfma_multi<4, 4>(W + wp_.n_ua, ob, fb, lane, xn[fb], a);
         if (valid) {
-            if (ob < 8) st4(cen + ob * 64 + 3 * 16 + 4 * g, a);                 // centre record slot kg = 3 (U)
-            else st4(nb + ((ob - 8) * 4 + g) * 16, a);                          // neighbour record array 0 (A)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);        // centre record slot kg = 3 (U)
+                else st4(nb + ((ob + j - 8) * 4 + g) * 16, a[j]);                  // neighbour record array 0 (A)
+            }
         }
     }
     // [G_c | C_c] = [W[:,129:161]; W[:,161:193]] p[c]
+#pragma unroll 1
+    for (int ob = 0; ob < 16; ob += 2) {
+        f32x4 a[2][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll 4
-        for (int ob = 0; ob < 16; ++ob) {
-            f32x4 a = f32x4{0, 0, 0, 0};
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int fb = 0; fb < 2; ++fb) a = mfma_block<2>(W + wp_.n_gc, ob, fb, lane, p[c][fb], a);
-            if (valid) {
-                if (ob < 8) st4(cen + ob * 64 + c * 16 + 4 * g, a);
-                else st4(nb + ((ob - 8) * 4 + g) * 16 + (1 + c) * 4, a);
-            }
+            for (int c = 0; c < 3; ++c) a[j][c] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+            const f32x4 w0 = ld4(W + wp_.n_gc + ((size_t)((ob + 0) * 2 + fb) * 64 + lane) * 4);
+            const f32x4 w1 = ld4(W + wp_.n_gc + ((size_t)((ob + 1) * 2 + fb) * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { a[0][c] = MFMA(w0[r], p[c][fb][r], a[0][c]); a[1][c] = MFMA(w1[r], p[c][fb][r], a[1][c]); }
+        }
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (ob < 8) st4(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
+                    else st4(nb + ((ob + j - 8) * 4 + g) * 16 + (1 + c) * 4, a[j][c]);
+                }
         }
     }
     // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12 (rows 12..15 of the last block are zero padding)   // :119
@@ -168,15 +198,11 @@ __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, Layer
 #pragma unroll
         for (int m = 0; m < 2; ++m) h[m] = ld4(W + wp_.n_bn0 + 16 * m + 4 * g);
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) h[m] = mfma_block<4>(W + wp_.n_n0, m, fb, lane, xn[fb], h[m]);
+        for (int fb = 0; fb < 4; ++fb) mfma_multi<2, 4>(W + wp_.n_n0, 0, fb, lane, xn[fb], h);
 #pragma unroll
         for (int m = 0; m < 2; ++m) { h[m] = elu4(h[m]); t[m] = ld4(W + wp_.n_bn1 + 16 * m + 4 * g); }
 #pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) t[m] = mfma_block<2>(W + wp_.n_n1, m, fb, lane, h[fb], t[m]);
+        for (int fb = 0; fb < 2; ++fb) mfma_multi<2, 2>(W + wp_.n_n1, 0, fb, lane, h[fb], t);
         f32x4 qq = ld4(W + wp_.n_bn2 + 4 * g);
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb) qq = mfma_block<2>(W + wp_.n_n2, 0, fb, lane, elu4(t[fb]), qq);
@@ -335,15 +361,36 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc2[m] = ld4(sm.w + EL_B2 + 16 * m + 4 * g);
 #pragma unroll
-                for (int fb = 0; fb < 4; ++fb) {
-                    const int net = fb >> 1, fbl = fb & 1;
+                for (int fbl = 0; fbl < 2; ++fbl) {
+                    // eq block fbl -> acc2[0..1], ep block 2+fbl -> acc2[2..3]: four independent chains interleaved
+                    f32x4 w[4];
 #pragma unroll
-                    for (int ml = 0; ml < 2; ++ml)
-                        acc2[net * 2 + ml] = mfma_block<2>(w2f + net * 4 * 256, ml, fbl, lane, h1[fb], acc2[net * 2 + ml]);
+                    for (int ml = 0; ml < 2; ++ml) {
+                        w[ml] = ld4(w2f + ((size_t)(ml * 2 + fbl) * 64 + lane) * 4);
+                        w[2 + ml] = ld4(w2f + 4 * 256 + ((size_t)(ml * 2 + fbl) * 64 + lane) * 4);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc2[0] = MFMA(w[0][r], h1[fbl][r], acc2[0]);
+                        acc2[2] = MFMA(w[2][r], h1[2 + fbl][r], acc2[2]);
+                        acc2[1] = MFMA(w[1][r], h1[fbl][r], acc2[1]);
+                        acc2[3] = MFMA(w[3][r], h1[2 + fbl][r], acc2[3]);
+                    }
                 }
-                f32x4 kacc = ld4(sm.w + EL_BK + 4 * g);
+                f32x4 kacc = ld4(sm.w + EL_BK + 4 * g), kacb = f32x4{0, 0, 0, 0};
+                {
+                    f32x4 h2k[4], wk[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) kacc = mfma_block<4>(w3k, 0, m, lane, elu4(acc2[m]), kacc);
+                    for (int m = 0; m < 4; ++m) { h2k[m] = elu4(acc2[m]); wk[m] = ld4(w3k + ((size_t)m * 64 + lane) * 4); }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            kacc = MFMA(wk[m][r], h2k[m][r], kacc);
+                            kacb = MFMA(wk[2 + m][r], h2k[2 + m][r], kacb);
+                        }
+                    kacc += kacb;
+                }
                 // lane (e, g): kacc[0..2] = key of part g for edge row; logits against Q[0] (scalar) or Q[1] (vector)
                 const int aMine = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
                 const float* Qv = rec_cen + (size_t)min(c0 + aMine, N1 - 1) * REC_CEN + 512 + (g == 0 ? 0 : 6);
@@ -438,9 +485,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
 #pragma unroll
             for (int ml = 0; ml < 4; ++ml) acc2[ml] = ld4(sm.w + EL_B2 + 64 + 16 * ml + 4 * g);
 #pragma unroll
-            for (int fbl = 0; fbl < 4; ++fbl)
-#pragma unroll
-                for (int ml = 0; ml < 4; ++ml) acc2[ml] = mfma_block<4>(w2f + 8 * 256, ml, fbl, lane, h1[fbl], acc2[ml]);
+            for (int fbl = 0; fbl < 4; ++fbl) mfma_multi<4, 4>(w2f + 8 * 256, 0, fbl, lane, h1[fbl], acc2);
             PHASE_MARK(3);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -462,14 +507,16 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
             for (int fo = 0; fo < 4; ++fo) {
                 const float b = sm.w[EL_B3V + 16 * fo + e];
                 v[fo] = f32x4{b, b, b, b};
+            }
 #pragma unroll
-                for (int ml = 0; ml < 4; ++ml) {
-                    const f32x4 wv = ld4(w3v + ((size_t)(fo * 4 + ml) * 64 + lane) * 4);
-                    v[fo] = MFMA(h2[ml][0], wv[0], v[fo]);
-                    v[fo] = MFMA(h2[ml][1], wv[1], v[fo]);
-                    v[fo] = MFMA(h2[ml][2], wv[2], v[fo]);
-                    v[fo] = MFMA(h2[ml][3], wv[3], v[fo]);
-                }
+            for (int ml = 0; ml < 4; ++ml) {
+                f32x4 wv[4];
+#pragma unroll
+                for (int fo = 0; fo < 4; ++fo) wv[fo] = ld4(w3v + ((size_t)(fo * 4 + ml) * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA(h2[ml][r], wv[fo][r], v[fo]);
             }
             PHASE_MARK(4);
 #pragma unroll
