@@ -13,7 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["pesto_schema.cpp", "pesto_kernels.hip", "pesto_layer_mfma.hip", "pesto_api.hip"]
 HEADERS = ["pesto_schema.h", "pesto_kernels.h", os.path.join("..", "..", "include", "pesto_hip.h")]
 OUT = os.path.join(HERE, "libpesto_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP vectoriser packs adjacent f32 adds/muls of the edge kernel into v_pk_*_f32 and pays for it with
+# ~5x more v_mov_b32 shuffles than it saves (665 -> 138 v_mov, mul+add re-fused into v_fmac) - measured +% in DESIGN.md
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 # developer variants: PESTO_EXTRA_CXXFLAGS="-DPESTO_PROFILE_PHASES" PESTO_LIB_TAG=prof -> libpesto_hip_prof.so (selected at
 # run time with PESTO_LIB=<path>); the default build is what ships
 EXTRA = os.environ.get("PESTO_EXTRA_CXXFLAGS", "").split()

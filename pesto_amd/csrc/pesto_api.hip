@@ -61,6 +61,7 @@ struct pesto_model {
     DevBuf rec_nb, rec_cen, zrec;          // MFMA path: per-atom neighbour / centre records and attention sums
     int impl = 2;                          // 2 = MFMA layer (default), 1 = LDS-tiled VALU layer (PESTO_IMPL=v1)
     int edge_blocks = 512;                 // persistent workgroups of the edge kernel (2 per CU)
+    int edge_variant = 0;                  // PESTO_EDGE_VARIANT: 0 = 4 waves/WG + prefetch, 1 = 12 waves/WG, 2 = 16 waves/WG
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     // state left by pesto_stage_unpack for pesto_stage_layer
     int64_t stage_N = -1;
@@ -133,7 +134,7 @@ int run_forward(pesto_model* m, hipStream_t st, int64_t N, int64_t R, int k, con
             launch_node(st, m->W, l > 0 ? &m->img.layers[l - 1] : nullptr, &m->img.layers[l], N1, q[0], p[0], m->zrec.as<float>(),
                         m->rec_nb.as<float>(), m->rec_cen.as<float>());
             launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(),
-                        m->rec_cen.as<float>(), m->zrec.as<float>(), m->edge_blocks);
+                        m->rec_cen.as<float>(), m->zrec.as<float>(), m->edge_blocks, m->edge_variant);
         }
         launch_node(st, m->W, &m->img.layers[m->cfg.n_layers - 1], nullptr, N1, q[0], p[0], m->zrec.as<float>(), m->rec_nb.as<float>(),
                     m->rec_cen.as<float>());
@@ -184,6 +185,7 @@ int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weight
     m->device = device;
     m->img = build_device_image(*cfg, weights);
     if (const char* impl = getenv("PESTO_IMPL")) m->impl = (strcmp(impl, "v1") == 0 || strcmp(impl, "1") == 0) ? 1 : 2;
+    if (const char* ev = getenv("PESTO_EDGE_VARIANT")) m->edge_variant = atoi(ev);
     if (const char* eb = getenv("PESTO_EDGE_BLOCKS")) { int v = atoi(eb); if (v > 0) m->edge_blocks = v; }
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&m->W, m->img.data.size() * sizeof(float));
@@ -336,7 +338,7 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
     if (m->impl == 2) {
         const LayerW* L = &m->img.layers[layer];
         launch_node(st, m->W, nullptr, L, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>());
-        launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->zrec.as<float>(), m->edge_blocks);
+        launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->zrec.as<float>(), m->edge_blocks, m->edge_variant);
         launch_node(st, m->W, L, nullptr, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>());
         q_res = m->q_a.p; p_res = m->p_a.p;
     } else {

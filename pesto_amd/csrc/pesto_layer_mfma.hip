@@ -238,9 +238,10 @@ struct EdgeWaveScratch {
     float zbuf[2][256];  // Zq | Zp staging per centre (two centres per tile when NN == 8)
     float z3buf[2][2][96];  // [centre sel][h][c*32+s]: sum_e w3[h][e] p_j(e), staged for the final combine
 };
+template <int WPB>
 struct EdgeSmem {
     float w[EDGE_LDS_FLOATS];
-    EdgeWaveScratch ws[4];
+    EdgeWaveScratch ws[WPB];
 };
 
 // Operands of the first edge layer for feature block fb of one 16-edge tile, fetched one or two blocks AHEAD of
@@ -290,20 +291,22 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
     return c;
 }
 
-template <int NN>
-__global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
+// WPB = waves per workgroup: 4 (two workgroups per CU, 2 waves/SIMD, needs the explicit cross-tile prefetch PF)
+// or 12 / 16 (one workgroup per CU, 3 / 4 waves per SIMD sharing one LDS copy of the layer constants).
+template <int NN, int WPB, bool PF>
+__global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
                                                  float* __restrict__ Z) {
     constexpr int A = 64 / NN;                 // centres per wave work item (64 edge rows)
     constexpr int TPC = NN >= 16 ? NN / 16 : 1;   // tiles per centre
-    __shared__ EdgeSmem sm;
+    __shared__ EdgeSmem<WPB> sm;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = lane & 15, g = lane >> 4;
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
         const f32x4* src = reinterpret_cast<const f32x4*>(W + lw.e_lds);
         f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
-        for (int k = threadIdx.x; k < EDGE_LDS_FLOATS / 4; k += 256) dst[k] = src[k];
+        for (int k = threadIdx.x; k < EDGE_LDS_FLOATS / 4; k += WPB * 64) dst[k] = src[k];
     }
     __syncthreads();
     EdgeWaveScratch& ws = sm.ws[wave];
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
     const int chunk = (n_work + 7) >> 3;
     const int w_end = min(n_work, (xcd + 1) * chunk);
     PHASE_DECL();
-    for (int work = xcd * chunk + jb * 4 + wave; work < w_end; work += nbx * 4) {
+    for (int work = xcd * chunk + jb * WPB + wave; work < w_end; work += nbx * WPB) {
         const int c0 = work * A;
         PHASE_INIT();
         {   // rows of this work item: lane = row
@@ -345,6 +348,10 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const TileCtx& tcc = tc[t & 1];
+                if (!PF && t > 0) {
+#pragma unroll
+                    for (int fb = 0; fb < 4; ++fb) ops[t & 1][fb] = l1_fetch<NN>(fb, lane, g, tcc.cenA, tcc.cenB, tcc.recj);
+                }
                 f32x4 h1[4];
 #pragma unroll
                 for (int fb = 0; fb < 4; ++fb)
@@ -353,8 +360,10 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
                 if (t < 3) {
                     tc[(t + 1) & 1] = tile_ctx<NN>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
                     const TileCtx& tn = tc[(t + 1) & 1];
+                    if (PF) {
 #pragma unroll
-                    for (int fb = 0; fb < 4; ++fb) ops[(t + 1) & 1][fb] = l1_fetch<NN>(fb, lane, g, tn.cenA, tn.cenB, tn.recj);
+                        for (int fb = 0; fb < 4; ++fb) ops[(t + 1) & 1][fb] = l1_fetch<NN>(fb, lane, g, tn.cenA, tn.cenB, tn.recj);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc2[4];
@@ -453,6 +462,10 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
         for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
         for (int t = 0; t < 4; ++t) {
             const TileCtx tc = tcn;
+            if (!PF && t > 0) {
+#pragma unroll
+                for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tc.cenA, tc.cenB, tc.recj);
+            }
             // neighbours' p_j of this tile (third block of Vp, :134) as 16-byte gathers: lane = (esub = lane / 24, quad =
             // lane % 24) reads floats 4*quad..+3 of the 96-vector of edges 2i + esub; issued first, consumed after the
             // first-layer VALU work below
@@ -477,8 +490,10 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
             // the first-layer operands of the NEXT tile fly during this tile's MFMA phase
             if (t < 3) {
                 tcn = tile_ctx<NN>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
+                if (PF) {
 #pragma unroll
-                for (int fbl = 0; fbl < 2; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
+                    for (int fbl = 0; fbl < 2; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             f32x4 acc2[4];
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void k_edge(const float* __restrict__ W, La
                 const float* pj = rec_nb + (size_t)ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)] * REC_NB + 512 + 4 * quad;
                 pv[i2] = esub < 2 ? ld4(pj) : f32x4{0, 0, 0, 0};
             }
-            if (t < 3) {   // second half of the next tile's first-layer operands: in flight during the value MFMAs
+            if (PF && t < 3) {   // second half of the next tile's first-layer operands: in flight during the value MFMAs
 #pragma unroll
                 for (int fbl = 2; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
             }
@@ -641,20 +656,29 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
                        finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
 }
 
-void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
-                 const float* rec_nb, const float* rec_cen, float* Z, int max_blocks) {
+template <int WPB, bool PF>
+static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
+                          const float* rec_nb, const float* rec_cen, float* Z, int max_blocks) {
     const int A = 64 / lw.nn;
     const int n_work = (N1 + A - 1) / A;
-    int blocks = ((n_work + 7) / 8 + 3) / 4 * 8;      // per-XCD share of the work items, 4 per workgroup, x 8 XCDs
+    int blocks = ((n_work + 7) / 8 + WPB - 1) / WPB * 8;   // per-XCD share of the work items, WPB per workgroup, x 8 XCDs
     if (blocks > max_blocks) blocks = max_blocks / 8 * 8;
     if (blocks < 8) blocks = 8;
-    const dim3 grid(blocks), block(256);
+    const dim3 grid(blocks), block(WPB * 64);
     switch (lw.nn) {
-        case 8: hipLaunchKernelGGL(k_edge<8>, grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
-        case 16: hipLaunchKernelGGL(k_edge<16>, grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
-        case 32: hipLaunchKernelGGL(k_edge<32>, grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
-        default: hipLaunchKernelGGL(k_edge<64>, grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
+        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
+        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
+        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
+        default: hipLaunchKernelGGL((k_edge<64, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
     }
+}
+
+// variant: 0 = 4 waves/workgroup, 2 workgroups/CU, explicit prefetch (default); 1 = 12 waves, 1 workgroup/CU; 2 = 16 waves
+void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
+                 const float* rec_nb, const float* rec_cen, float* Z, int max_blocks, int variant) {
+    if (variant == 1) launch_edge_t<12, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, 256);
+    else if (variant == 2) launch_edge_t<16, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, 256);
+    else launch_edge_t<4, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, max_blocks);
 }
 
 }  // namespace pesto
