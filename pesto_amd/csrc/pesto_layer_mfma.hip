@@ -21,15 +21,24 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "pesto_kernels.h"
 
 namespace pesto {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef PESTO_ABL_NOMFMA   // ablation: the MFMA becomes one VALU op keeping the data dependence
+#define MFMA(a, b, c) ((c) + (a) * (b))
+#else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
 
+#ifdef PESTO_ABL_NOELU
+__device__ __forceinline__ float elu_f(float x) { return x; }
+#else
 __device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+#endif
 __device__ __forceinline__ f32x4 elu4(f32x4 v) { return f32x4{elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3])}; }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -287,7 +296,11 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
     const float bg = g == 0 ? c.rx : (g == 1 ? c.ry : (g == 2 ? c.rz : 1.0f));
     c.bgA = (NN == 8 && e >= 8) ? 0.0f : bg;
     c.bgB = (NN == 8 && e >= 8) ? bg : 0.0f;
+#ifdef PESTO_ABL_NOGATHER
+    c.recj = rec_nb + (size_t)(row & 7) * REC_NB;      // ablation: every edge reads one of 8 hot records
+#else
     c.recj = rec_nb + (size_t)ws.nb[row] * REC_NB;
+#endif
     return c;
 }
 
@@ -297,7 +310,7 @@ template <int NN, int WPB, bool PF>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
-                                                 float* __restrict__ Z) {
+                                                 float* __restrict__ Z, int stagger) {
     constexpr int A = 64 / NN;                 // centres per wave work item (64 edge rows)
     constexpr int TPC = NN >= 16 ? NN / 16 : 1;   // tiles per centre
     __shared__ EdgeSmem<WPB> sm;
@@ -309,6 +322,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         for (int k = threadIdx.x; k < EDGE_LDS_FLOATS / 4; k += WPB * 64) dst[k] = src[k];
     }
     __syncthreads();
+    if (stagger > 0) {   // experiment: de-phase the two waves that share a SIMD (hardware wave slot parity)
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;   // HW_REG_HW_ID.wave_id
+        if (slot & 1) for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(32);
+    }
     EdgeWaveScratch& ws = sm.ws[wave];
     const float* w2f = sm.w + EL_W2F;
     const float* w3k = sm.w + EL_W3K;
@@ -656,9 +673,11 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
                        finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
 }
 
+static int g_stagger = -1;
 template <int WPB, bool PF>
 static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                           const float* rec_nb, const float* rec_cen, float* Z, int max_blocks) {
+    if (g_stagger < 0) { const char* e = getenv("PESTO_STAGGER"); g_stagger = e ? atoi(e) : 0; }
     const int A = 64 / lw.nn;
     const int n_work = (N1 + A - 1) / A;
     int blocks = ((n_work + 7) / 8 + WPB - 1) / WPB * 8;   // per-XCD share of the work items, WPB per workgroup, x 8 XCDs
@@ -666,10 +685,10 @@ static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int 
     if (blocks < 8) blocks = 8;
     const dim3 grid(blocks), block(WPB * 64);
     switch (lw.nn) {
-        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
-        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
-        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
-        default: hipLaunchKernelGGL((k_edge<64, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z); break;
+        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
+        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
+        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
+        default: hipLaunchKernelGGL((k_edge<64, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
     }
 }
 
