@@ -28,6 +28,24 @@
 namespace pesto {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+// fp32 -> (hi, lo) f16 pair with x = hi + lo to ~2^-21 relative: hi = rtz16(x), lo = rtz16(x - hi) (the residual is
+// exact in fp32). Two 16-feature blocks (4 + 4 values of this lane) form the 8 k-values one lane feeds to
+// v_mfma_f32_16x16x32_f16. Three MFMAs (hi*hi, lo*hi, hi*lo) then reproduce the fp32 product to ~2^-21.
+__device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v[j], v[j + 1]);
+        const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(v[j] - (float)h[0], v[j + 1] - (float)h[1]);
+        hi[j] = (_Float16)h[0]; hi[j + 1] = (_Float16)h[1];
+        lo[j] = (_Float16)l[0]; lo[j + 1] = (_Float16)l[1];
+    }
+}
+__device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast<const f16x8*>(p); }
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 #ifdef PESTO_ABL_NOMFMA   // ablation: the MFMA becomes one VALU op keeping the data dependence
 #define MFMA(a, b, c) ((c) + (a) * (b))
 #else
@@ -306,7 +324,7 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
 
 // WPB = waves per workgroup: 4 (two workgroups per CU, 2 waves/SIMD, needs the explicit cross-tile prefetch PF)
 // or 12 / 16 (one workgroup per CU, 3 / 4 waves per SIMD sharing one LDS copy of the layer constants).
-template <int NN, int WPB, bool PF>
+template <int NN, int WPB, bool PF, bool F16>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
@@ -317,7 +335,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = lane & 15, g = lane >> 4;
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
-        const f32x4* src = reinterpret_cast<const f32x4*>(W + lw.e_lds);
+        const f32x4* src = reinterpret_cast<const f32x4*>(W + (F16 ? lw.e_lds16 : lw.e_lds));
         f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
         for (int k = threadIdx.x; k < EDGE_LDS_FLOATS / 4; k += WPB * 64) dst[k] = src[k];
     }
@@ -516,8 +534,28 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             f32x4 acc2[4];
 #pragma unroll
             for (int ml = 0; ml < 4; ++ml) acc2[ml] = ld4(sm.w + EL_B2 + 64 + 16 * ml + 4 * g);
+            if (F16) {   // value network layer 2 on v_mfma_f32_16x16x32_f16, operands split into f16 hi/lo pairs
 #pragma unroll
-            for (int fbl = 0; fbl < 4; ++fbl) mfma_multi<4, 4>(w2f + 8 * 256, 0, fbl, lane, h1[fbl], acc2);
+                for (int kgp = 0; kgp < 2; ++kgp) {
+                    f16x8 xh, xl;
+                    split8(h1[2 * kgp], h1[2 * kgp + 1], xh, xl);
+                    f16x8 wh[4], wl[4];
+#pragma unroll
+                    for (int ml = 0; ml < 4; ++ml) {
+                        const float* fr = w2f + 8 * 256 + (size_t)((ml * 2 + kgp) * 2) * 256 + lane * 4;
+                        wh[ml] = ld8h(fr); wl[ml] = ld8h(fr + 256);
+                    }
+#pragma unroll
+                    for (int ml = 0; ml < 4; ++ml) acc2[ml] = MFMA16(wh[ml], xh, acc2[ml]);
+#pragma unroll
+                    for (int ml = 0; ml < 4; ++ml) acc2[ml] = MFMA16(wh[ml], xl, acc2[ml]);
+#pragma unroll
+                    for (int ml = 0; ml < 4; ++ml) acc2[ml] = MFMA16(wl[ml], xh, acc2[ml]);
+                }
+            } else {
+#pragma unroll
+                for (int fbl = 0; fbl < 4; ++fbl) mfma_multi<4, 4>(w2f + 8 * 256, 0, fbl, lane, h1[fbl], acc2);
+            }
             PHASE_MARK(3);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -540,15 +578,35 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 const float b = sm.w[EL_B3V + 16 * fo + e];
                 v[fo] = f32x4{b, b, b, b};
             }
+            if (F16) {
 #pragma unroll
-            for (int ml = 0; ml < 4; ++ml) {
-                f32x4 wv[4];
+                for (int kgp = 0; kgp < 2; ++kgp) {
+                    f16x8 ah, al;
+                    split8(h2[2 * kgp], h2[2 * kgp + 1], ah, al);
+                    f16x8 bh[4], bl[4];
 #pragma unroll
-                for (int fo = 0; fo < 4; ++fo) wv[fo] = ld4(w3v + ((size_t)(fo * 4 + ml) * 64 + lane) * 4);
+                    for (int fo = 0; fo < 4; ++fo) {
+                        const float* fr = w3v + (size_t)((fo * 2 + kgp) * 2) * 256 + lane * 4;
+                        bh[fo] = ld8h(fr); bl[fo] = ld8h(fr + 256);
+                    }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA16(ah, bh[fo], v[fo]);
 #pragma unroll
-                    for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA(h2[ml][r], wv[fo][r], v[fo]);
+                    for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA16(al, bh[fo], v[fo]);
+#pragma unroll
+                    for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA16(ah, bl[fo], v[fo]);
+                }
+            } else {
+#pragma unroll
+                for (int ml = 0; ml < 4; ++ml) {
+                    f32x4 wv[4];
+#pragma unroll
+                    for (int fo = 0; fo < 4; ++fo) wv[fo] = ld4(w3v + ((size_t)(fo * 4 + ml) * 64 + lane) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA(h2[ml][r], wv[fo][r], v[fo]);
+                }
             }
             PHASE_MARK(4);
 #pragma unroll
@@ -674,7 +732,7 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
 }
 
 static int g_stagger = -1;
-template <int WPB, bool PF>
+template <int WPB, bool PF, bool F16>
 static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                           const float* rec_nb, const float* rec_cen, float* Z, int max_blocks) {
     if (g_stagger < 0) { const char* e = getenv("PESTO_STAGGER"); g_stagger = e ? atoi(e) : 0; }
@@ -685,19 +743,18 @@ static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int 
     if (blocks < 8) blocks = 8;
     const dim3 grid(blocks), block(WPB * 64);
     switch (lw.nn) {
-        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
-        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
-        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
-        default: hipLaunchKernelGGL((k_edge<64, WPB, PF>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
+        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
+        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
+        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
+        default: hipLaunchKernelGGL((k_edge<64, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
     }
 }
 
-// variant: 0 = 4 waves/workgroup, 2 workgroups/CU, explicit prefetch (default); 1 = 12 waves, 1 workgroup/CU; 2 = 16 waves
+// variant 0 (default): value network on f16-split MFMA; variant 1: everything on exact fp32 MFMA
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, float* Z, int max_blocks, int variant) {
-    if (variant == 1) launch_edge_t<12, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, 256);
-    else if (variant == 2) launch_edge_t<16, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, 256);
-    else launch_edge_t<4, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, max_blocks);
+    if (variant == 1) launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, max_blocks);   // exact fp32 MFMA
+    else launch_edge_t<4, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, max_blocks);                // f16-split value network
 }
 
 }  // namespace pesto

@@ -1,6 +1,8 @@
 // pesto_schema.cpp - host blob schema and device weight image construction (host code only).
 #include "pesto_schema.h"
 
+#include <cstring>
+
 namespace pesto {
 
 bool config_ok(const pesto_config* c) {
@@ -84,6 +86,24 @@ int32_t put_frags(std::vector<float>& img, const Mat& M, int n_m, int n_fb, int 
                 for (int r = 0; r < 4; ++r)
                     img.push_back(M.get(row0 + 16 * m + (lane & 15), col0 + 16 * fb + 4 * (lane >> 4) + r));
     return off;
+}
+// f16 hi/lo fragment table for v_mfma_f32_16x16x32_f16 over the image (two halves per float slot):
+// [m][kgroup][hi|lo][lane][j 0..7] = split(W[16m + (lane&15)][16(2 kgroup + j/4) + 4(lane>>4) + j%4]), w = hi + lo
+// with hi = f16(w) (round to nearest), lo = f16(w - hi): w is represented to ~2^-22 relative.
+void put_frags_f16(std::vector<float>& img, const Mat& M, int n_m, int n_kg) {
+    std::vector<_Float16> h;
+    for (int m = 0; m < n_m; ++m)
+        for (int kgp = 0; kgp < n_kg; ++kgp)
+            for (int part = 0; part < 2; ++part)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float w = M.get(16 * m + (lane & 15), 16 * (2 * kgp + (j >> 2)) + 4 * (lane >> 4) + (j & 3));
+                        const _Float16 hi = (_Float16)w;
+                        h.push_back(part == 0 ? hi : (_Float16)(w - (float)hi));
+                    }
+    const size_t off = img.size();
+    img.resize(off + h.size() / 2);
+    memcpy(&img[off], h.data(), h.size() * sizeof(_Float16));
 }
 int32_t put_vec(std::vector<float>& img, const float* src, int n, int pad_to = 0) {
     int32_t off = (int32_t)img.size();
@@ -195,6 +215,20 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
             std::vector<float> wd(128);
             for (int f = 0; f < 128; ++f) wd[f] = W1.get(f, 0);
             put_vec(img, wd.data(), 128);
+        }
+        {   // f16-split variant of the same LDS image: only the value network's big GEMMs change representation
+            pad16(img);
+            W.e_lds16 = (int32_t)img.size();
+            img.insert(img.end(), img.begin() + W.e_lds, img.begin() + W.e_lds + EDGE_LDS_FLOATS);
+            Mat Wev2(64, 64), Wv3(64, 64);
+            put_block(Wev2, 0, 0, blob, L.evm.l[1], 0, 64);
+            put_block(Wv3, 0, 0, blob, L.evm.l[2], 0, 64);
+            std::vector<float> tmp;
+            put_frags_f16(tmp, Wev2, 4, 2);              // 4 out-blocks x 2 k-groups x (hi, lo) x 256 floats = 4096 floats
+            std::copy(tmp.begin(), tmp.end(), img.begin() + W.e_lds16 + EL_W2F + 8 * 256);
+            tmp.clear();
+            put_frags_f16(tmp, Wv3, 4, 2);
+            std::copy(tmp.begin(), tmp.end(), img.begin() + W.e_lds16 + EL_W3V);
         }
         // node kernel: finish (qpm, ppm)
         {

@@ -38,6 +38,8 @@ struct LayerW {
     // [out-block m][in-block fb][lane 0..63][r 0..3]: value W[16m + (lane&15)][16fb + 4(lane>>4) + r], so one
     // float4 per lane feeds the four k-steps r of mfma_f32_16x16x4 for (m, fb).
     int32_t e_lds;              // edge-kernel LDS image, EDGE_LDS_FLOATS contiguous floats (layout: EdgeLds below)
+    int32_t e_lds16;            // same image with the value network's layer-2/3 fragments as f16 hi/lo pairs for
+                                // v_mfma_f32_16x16x32_f16: [m][kgroup][hi|lo][lane][8 halves], k(kg, j) = 16(2 kgroup + j/4) + 4kg + j%4
     int32_t n_q0, n_bq0, n_q1, n_bq1, n_q2, n_bq2, n_pp;   // qpm frags [2][4],[2][2],[2][2] + biases[32]; ppm frags [2][4]
     int32_t n_ua, n_b1, n_gc;                               // [U|A] frags [16][4], b1[128]; [G|C] frags [16][2]
     int32_t n_n0, n_bn0, n_n1, n_bn1, n_n2, n_bn2;          // nqm frags [2][4],[2][2],[1][2] + biases (last padded to 16)
