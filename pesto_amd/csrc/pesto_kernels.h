@@ -13,7 +13,7 @@ void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, c
                      const float* q_in, const float* p_in, float* q_out, float* p_out);
 // MFMA layer (pesto_layer_mfma.hip): per-atom node kernel (finish previous layer / prepare records) + edge kernel
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
-                 const float* Z, float* rec_nb, float* rec_cen);
+                 const float* Z, float* rec_nb, float* rec_cen, int variant);
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, float* Z, int max_blocks, int variant);
 void debug_print_phase_cycles();   // no-op unless built with -DPESTO_PROFILE_PHASES

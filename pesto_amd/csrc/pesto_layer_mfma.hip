@@ -244,6 +244,190 @@ __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, Layer
     }
 }
 
+// NM output blocks advanced through k-group kgp (two 16-feature input blocks) on v_mfma_f32_16x16x32_f16 with both
+// operands split into f16 hi/lo pairs: acc += wh*xh + wh*xl + wl*xh  (the dropped wl*xl term is ~2^-22 relative).
+// Fragment table layout: [m][kgroup][hi|lo][lane][8 halves] (pesto_schema.cpp::put_frags_f16).
+template <int NM>
+__device__ __forceinline__ void mfma16_multi(const float* __restrict__ wf, int m0, int nkg, int kgp, int lane, f16x8 xh, f16x8 xl,
+                                             f32x4* acc) {
+    f16x8 wh[NM], wl[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const float* fr = wf + (size_t)(((m0 + m) * nkg + kgp) * 2) * 256 + lane * 4;
+        wh[m] = ld8h(fr); wl[m] = ld8h(fr + 256);
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m] = MFMA16(wh[m], xh, acc[m]);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m] = MFMA16(wh[m], xl, acc[m]);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m] = MFMA16(wl[m], xh, acc[m]);
+}
+
+// node kernel on the f16-split MFMA path (same contract as k_node; 321 f16 MFMAs instead of 856 fp32 MFMAs per 16 atoms)
+__global__ __launch_bounds__(256) void k_node16(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
+                                                int N1, float* __restrict__ q_state, float* __restrict__ p_state,
+                                                const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen) {
+    const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
+    const int n_tiles = (N1 + 15) >> 4, chunk = (n_tiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile = xcd * chunk + jb * 4 + (threadIdx.x >> 6);
+    if (tile >= min(n_tiles, (xcd + 1) * chunk)) return;
+    const int i_raw = tile * 16 + e;
+    const bool valid = i_raw < N1;
+    const int i = valid ? i_raw : N1 - 1;
+
+    f32x4 q[2], p[3][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        q[m] = ld4(q_state + (size_t)i * S + 16 * m + 4 * g);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c][m] = ld4(p_state + (size_t)i * 96 + c * 32 + 16 * m + 4 * g);
+    }
+    f16x8 xh, xl;
+    if (do_finish) {
+        const float* zr = Z + (size_t)i * REC_Z;
+        f32x4 h[2], t[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) h[m] = ld4(W + wf_.n_bq0 + 16 * m + 4 * g);
+#pragma unroll
+        for (int kgp = 0; kgp < 2; ++kgp) {
+            split8(ld4(zr + 32 * kgp + 4 * g), ld4(zr + 32 * kgp + 16 + 4 * g), xh, xl);
+            mfma16_multi<2>(W + wf_.h_q0, 0, 2, kgp, lane, xh, xl, h);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { h[m] = elu4(h[m]); t[m] = ld4(W + wf_.n_bq1 + 16 * m + 4 * g); }
+        split8(h[0], h[1], xh, xl);
+        mfma16_multi<2>(W + wf_.h_q1, 0, 1, 0, lane, xh, xl, t);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { t[m] = elu4(t[m]); h[m] = ld4(W + wf_.n_bq2 + 16 * m + 4 * g); }
+        split8(t[0], t[1], xh, xl);
+        mfma16_multi<2>(W + wf_.h_q2, 0, 1, 0, lane, xh, xl, h);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) q[m] += h[m];
+        {   // ppm: the three xyz components share each weight fragment (6 independent accumulators)
+            f32x4 a[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a[c][0] = f32x4{0, 0, 0, 0}; a[c][1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+            for (int kgp = 0; kgp < 2; ++kgp) {
+                f16x8 wh[2], wl[2], zh[3], zl[3];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const float* fr = W + wf_.h_pp + (size_t)((m * 2 + kgp) * 2) * 256 + lane * 4;
+                    wh[m] = ld8h(fr); wl[m] = ld8h(fr + 256);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    split8(ld4(zr + 64 + c * 64 + 32 * kgp + 4 * g), ld4(zr + 64 + c * 64 + 32 * kgp + 16 + 4 * g), zh[c], zl[c]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) a[c][m] = MFMA16(wh[m], zh[c], a[c][m]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) a[c][m] = MFMA16(wh[m], zl[c], a[c][m]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) a[c][m] = MFMA16(wl[m], zh[c], a[c][m]);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { p[c][0] += a[c][0]; p[c][1] += a[c][1]; }
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { q[m] = f32x4{0, 0, 0, 0}; p[0][m] = q[m]; p[1][m] = q[m]; p[2][m] = q[m]; }
+        }
+        if (valid) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                st4(q_state + (size_t)i * S + 16 * m + 4 * g, q[m]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) st4(p_state + (size_t)i * 96 + c * 32 + 16 * m + 4 * g, p[c][m]);
+            }
+        }
+    }
+    if (!do_prep) return;
+
+    f32x4 pn[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            pn[m][r] = sqrtf(p[0][m][r] * p[0][m][r] + p[1][m][r] * p[1][m][r] + p[2][m][r] * p[2][m][r]);
+    f16x8 xnh[2], xnl[2], ph[3], pl[3];
+    split8(q[0], q[1], xnh[0], xnl[0]);
+    split8(pn[0], pn[1], xnh[1], xnl[1]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) split8(p[c][0], p[c][1], ph[c], pl[c]);
+
+    float* cen = rec_cen + (size_t)i * REC_CEN;
+    float* nb = rec_nb + (size_t)i * REC_NB;
+#pragma unroll 1
+    for (int ob = 0; ob < 16; ob += 4) {
+        f32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = ob < 8 ? ld4(W + wp_.n_b1 + 16 * (ob + j) + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<4>(W + wp_.h_ua, ob, 2, kgp, lane, xnh[kgp], xnl[kgp], a);
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);
+                else st4(nb + ((ob + j - 8) * 4 + g) * 16, a[j]);
+            }
+        }
+    }
+#pragma unroll 1
+    for (int ob = 0; ob < 16; ob += 2) {
+        f32x4 a[2][3];
+        f16x8 wh[2], wl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* fr = W + wp_.h_gc + (size_t)((ob + j) * 2) * 256 + lane * 4;
+            wh[j] = ld8h(fr); wl[j] = ld8h(fr + 256);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[j][c] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wh[0], ph[c], a[0][c]); a[1][c] = MFMA16(wh[1], ph[c], a[1][c]); }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wh[0], pl[c], a[0][c]); a[1][c] = MFMA16(wh[1], pl[c], a[1][c]); }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wl[0], ph[c], a[0][c]); a[1][c] = MFMA16(wl[1], ph[c], a[1][c]); }
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (ob < 8) st4(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
+                    else st4(nb + ((ob + j - 8) * 4 + g) * 16 + (1 + c) * 4, a[j][c]);
+                }
+        }
+    }
+    {
+        f32x4 h[2], t[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { h[m] = ld4(W + wp_.n_bn0 + 16 * m + 4 * g); t[m] = ld4(W + wp_.n_bn1 + 16 * m + 4 * g); }
+#pragma unroll
+        for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<2>(W + wp_.h_n0, 0, 2, kgp, lane, xnh[kgp], xnl[kgp], h);
+        split8(elu4(h[0]), elu4(h[1]), xh, xl);
+        mfma16_multi<2>(W + wp_.h_n1, 0, 1, 0, lane, xh, xl, t);
+        f32x4 qq[1] = {ld4(W + wp_.n_bn2 + 4 * g)};
+        split8(elu4(t[0]), elu4(t[1]), xh, xl);
+        mfma16_multi<1>(W + wp_.h_n2, 0, 1, 0, lane, xh, xl, qq);
+        if (valid) st4(cen + 512 + 4 * g, qq[0]);
+    }
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) st4(nb + 512 + c * 32 + 16 * m + 4 * g, p[c][m]);
+    }
+}
+
 // =============================================================================================== edge kernel
 #ifdef PESTO_PROFILE_PHASES   // developer build: per-phase wave cycles (s_memtime), printed by pesto_destroy
 __device__ unsigned long long g_phase_cycles[8];
@@ -724,10 +908,10 @@ void debug_print_phase_cycles() {
 
 // =============================================================================================== launchers
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
-                 const float* Z, float* rec_nb, float* rec_cen) {
+                 const float* Z, float* rec_nb, float* rec_cen, int variant) {
     const int tiles = (N1 + 15) / 16, chunk = (tiles + 7) / 8;
     const LayerW dummy{};
-    hipLaunchKernelGGL(k_node, dim3((chunk + 3) / 4 * 8), dim3(256), 0, st, W, finish ? *finish : dummy, prep ? *prep : dummy,
+    hipLaunchKernelGGL(variant == 1 ? k_node : k_node16, dim3((chunk + 3) / 4 * 8), dim3(256), 0, st, W, finish ? *finish : dummy, prep ? *prep : dummy,
                        finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
 }
 

@@ -90,7 +90,7 @@ int32_t put_frags(std::vector<float>& img, const Mat& M, int n_m, int n_fb, int 
 // f16 hi/lo fragment table for v_mfma_f32_16x16x32_f16 over the image (two halves per float slot):
 // [m][kgroup][hi|lo][lane][j 0..7] = split(W[16m + (lane&15)][16(2 kgroup + j/4) + 4(lane>>4) + j%4]), w = hi + lo
 // with hi = f16(w) (round to nearest), lo = f16(w - hi): w is represented to ~2^-22 relative.
-void put_frags_f16(std::vector<float>& img, const Mat& M, int n_m, int n_kg) {
+int32_t put_frags_f16(std::vector<float>& img, const Mat& M, int n_m, int n_kg) {
     std::vector<_Float16> h;
     for (int m = 0; m < n_m; ++m)
         for (int kgp = 0; kgp < n_kg; ++kgp)
@@ -104,6 +104,7 @@ void put_frags_f16(std::vector<float>& img, const Mat& M, int n_m, int n_kg) {
     const size_t off = img.size();
     img.resize(off + h.size() / 2);
     memcpy(&img[off], h.data(), h.size() * sizeof(_Float16));
+    return (int32_t)off;
 }
 int32_t put_vec(std::vector<float>& img, const float* src, int n, int pad_to = 0) {
     int32_t off = (int32_t)img.size();
@@ -237,6 +238,8 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
             put_block(M1, 0, 0, blob, L.qpm.l[1], 0, 32);
             put_block(M2, 0, 0, blob, L.qpm.l[2], 0, 32);
             put_block(Mp, 0, 0, blob, L.ppm, 0, 64);
+            W.h_q0 = put_frags_f16(img, M0, 2, 2); W.h_q1 = put_frags_f16(img, M1, 2, 1); W.h_q2 = put_frags_f16(img, M2, 2, 1);
+            W.h_pp = put_frags_f16(img, Mp, 2, 2);
             W.n_q0 = put_frags(img, M0, 2, 4); W.n_bq0 = put_vec(img, blob + L.qpm.l[0].b, 32);
             W.n_q1 = put_frags(img, M1, 2, 2); W.n_bq1 = put_vec(img, blob + L.qpm.l[1].b, 32);
             W.n_q2 = put_frags(img, M2, 2, 2); W.n_bq2 = put_vec(img, blob + L.qpm.l[2].b, 32);
@@ -249,6 +252,8 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
                 for (int c = 0; c < 64; ++c) { Mua.at(f, c) = W1.get(f, 1 + c); Mua.at(128 + f, c) = W1.get(f, 65 + c); }
             for (int f = 0; f < 128; ++f)
                 for (int c = 0; c < 32; ++c) { Mgc.at(f, c) = W1.get(f, 129 + c); Mgc.at(128 + f, c) = W1.get(f, 161 + c); }
+            W.h_ua = put_frags_f16(img, Mua, 16, 2);
+            W.h_gc = put_frags_f16(img, Mgc, 16, 1);
             W.n_ua = put_frags(img, Mua, 16, 4);
             W.n_b1 = put_vec(img, b1.data(), 128);
             W.n_gc = put_frags(img, Mgc, 16, 2);
@@ -256,6 +261,7 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
             put_block(N0, 0, 0, blob, L.nqm.l[0], 0, 64);
             put_block(N1, 0, 0, blob, L.nqm.l[1], 0, 32);
             put_block(N2, 0, 0, blob, L.nqm.l[2], 0, 32);
+            W.h_n0 = put_frags_f16(img, N0, 2, 2); W.h_n1 = put_frags_f16(img, N1, 2, 1); W.h_n2 = put_frags_f16(img, N2, 1, 1);
             W.n_n0 = put_frags(img, N0, 2, 4); W.n_bn0 = put_vec(img, blob + L.nqm.l[0].b, 32);
             W.n_n1 = put_frags(img, N1, 2, 2); W.n_bn1 = put_vec(img, blob + L.nqm.l[1].b, 32);
             W.n_n2 = put_frags(img, N2, 1, 2); W.n_bn2 = put_vec(img, blob + L.nqm.l[2].b, 12, 16);

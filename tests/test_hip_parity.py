@@ -1,6 +1,7 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against (a) golden vectors captured from the
 reference PyTorch CPU path and (b) the CPU oracle on the same seeded inputs.
-Tolerances: per-stage 1e-5 abs, whole forward 1e-4 abs on z (the north-star's fp32 bound)."""
+Tolerances: whole forward 1e-4 abs on z (the north-star's fp32 bound; measured 1-3e-5); per stage 1e-5 abs for the
+small stages and 1e-6 of the state scale for a layer (see stage_tol)."""
 import numpy as np
 import pytest
 
@@ -10,11 +11,19 @@ from pesto_amd.config import CONFIGS
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["mfma", "v1"])
+@pytest.fixture(params=["mfma", "mfma_exact", "v1"])
 def impl(request, monkeypatch):
-    """Both layer implementations: the MFMA path (default, shipped) and the LDS-tiled VALU path (PESTO_IMPL=v1)."""
+    """All layer implementations: the shipped MFMA path (big GEMMs on f16-split MFMA), the same kernels on exact fp32
+    MFMA (PESTO_EDGE_VARIANT=1) and the LDS-tiled VALU path (PESTO_IMPL=v1)."""
     monkeypatch.setenv("PESTO_IMPL", "v1" if request.param == "v1" else "v2")
+    monkeypatch.setenv("PESTO_EDGE_VARIANT", "1" if request.param == "mfma_exact" else "0")
     return request.param
+
+
+def stage_tol(ref):
+    """Per-stage bound: 1e-6 relative to the largest reference magnitude (+1e-6): a few fp32 ulps of the state scale.
+    (States reach |p| ~ 27 at layer 15; a fixed 1e-5 would be 0.4 ppm of that, below fp32 re-association noise.)"""
+    return 1e-6 * (1.0 + float(np.abs(ref).max()))
 
 
 def _model(tag):
@@ -47,8 +56,8 @@ def test_stage_layer(layer, impl):
     m = _model("i_v4_0")
     m.stage_unpack(g["X"], g["ids_topk"].astype(np.int32))
     q, p = m.stage_layer(layer, g[f"L{layer}_q_in"], g[f"L{layer}_p_in"])
-    assert np.abs(q - g[f"L{layer}_q_out"]).max() < 1e-5
-    assert np.abs(p - g[f"L{layer}_p_out"]).max() < 1e-5
+    assert np.abs(q - g[f"L{layer}_q_out"]).max() < stage_tol(g[f"L{layer}_q_out"])
+    assert np.abs(p - g[f"L{layer}_p_out"]).max() < stage_tol(g[f"L{layer}_p_out"])
     assert np.all(q[0] == 0) and np.all(p[0] == 0)
 
 
