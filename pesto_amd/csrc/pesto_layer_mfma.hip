@@ -588,25 +588,55 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 f32x4 acc2[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc2[m] = ld4(sm.w + EL_B2 + 16 * m + 4 * g);
+                f32x4 kacc = ld4(sm.w + EL_BK + 4 * g);
+                if (F16) {   // key networks on f16-split MFMA: eq (h1 blocks 0,1) and ep (blocks 2,3), K = 32 each
+                    f16x8 xh[2], xl[2], wh[4], wl[4];
+                    split8(h1[0], h1[1], xh[0], xl[0]);
+                    split8(h1[2], h1[3], xh[1], xl[1]);
 #pragma unroll
-                for (int fbl = 0; fbl < 2; ++fbl) {
-                    // eq block fbl -> acc2[0..1], ep block 2+fbl -> acc2[2..3]: four independent chains interleaved
-                    f32x4 w[4];
-#pragma unroll
-                    for (int ml = 0; ml < 2; ++ml) {
-                        w[ml] = ld4(w2f + ((size_t)(ml * 2 + fbl) * 64 + lane) * 4);
-                        w[2 + ml] = ld4(w2f + 4 * 256 + ((size_t)(ml * 2 + fbl) * 64 + lane) * 4);
+                    for (int a = 0; a < 4; ++a) {      // a = net * 2 + ml; fragment order [net][ml][hi|lo]
+                        const float* fr = w2f + (size_t)(a * 2) * 256 + lane * 4;
+                        wh[a] = ld8h(fr); wl[a] = ld8h(fr + 256);
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc2[0] = MFMA(w[0][r], h1[fbl][r], acc2[0]);
-                        acc2[2] = MFMA(w[2][r], h1[2 + fbl][r], acc2[2]);
-                        acc2[1] = MFMA(w[1][r], h1[fbl][r], acc2[1]);
-                        acc2[3] = MFMA(w[3][r], h1[2 + fbl][r], acc2[3]);
+                    for (int a = 0; a < 4; ++a) acc2[a] = MFMA16(wh[a], xh[a >> 1], acc2[a]);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc2[a] = MFMA16(wh[a], xl[a >> 1], acc2[a]);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc2[a] = MFMA16(wl[a], xh[a >> 1], acc2[a]);
+                    // keys: K = 64 = k-group 0 (eq h2 blocks) + k-group 1 (ep h2 blocks); two accumulators, summed
+                    f32x4 kacb = f32x4{0, 0, 0, 0};
+                    f16x8 kh[2], kl[2];
+                    split8(elu4(acc2[0]), elu4(acc2[1]), xh[0], xl[0]);
+                    split8(elu4(acc2[2]), elu4(acc2[3]), xh[1], xl[1]);
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) {
+                        const float* fr = w3k + (size_t)(kgp * 2) * 256 + lane * 4;
+                        kh[kgp] = ld8h(fr); kl[kgp] = ld8h(fr + 256);
                     }
-                }
-                f32x4 kacc = ld4(sm.w + EL_BK + 4 * g), kacb = f32x4{0, 0, 0, 0};
-                {
+                    kacc = MFMA16(kh[0], xh[0], kacc); kacb = MFMA16(kh[1], xh[1], kacb);
+                    kacc = MFMA16(kh[0], xl[0], kacc); kacb = MFMA16(kh[1], xl[1], kacb);
+                    kacc = MFMA16(kl[0], xh[0], kacc); kacb = MFMA16(kl[1], xh[1], kacb);
+                    kacc += kacb;
+                } else {
+#pragma unroll
+                    for (int fbl = 0; fbl < 2; ++fbl) {
+                        // eq block fbl -> acc2[0..1], ep block 2+fbl -> acc2[2..3]: four independent chains interleaved
+                        f32x4 w[4];
+#pragma unroll
+                        for (int ml = 0; ml < 2; ++ml) {
+                            w[ml] = ld4(w2f + ((size_t)(ml * 2 + fbl) * 64 + lane) * 4);
+                            w[2 + ml] = ld4(w2f + 4 * 256 + ((size_t)(ml * 2 + fbl) * 64 + lane) * 4);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc2[0] = MFMA(w[0][r], h1[fbl][r], acc2[0]);
+                            acc2[2] = MFMA(w[2][r], h1[2 + fbl][r], acc2[2]);
+                            acc2[1] = MFMA(w[1][r], h1[fbl][r], acc2[1]);
+                            acc2[3] = MFMA(w[3][r], h1[2 + fbl][r], acc2[3]);
+                        }
+                    }
+                    f32x4 kacb = f32x4{0, 0, 0, 0};
                     f32x4 h2k[4], wk[4];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) { h2k[m] = elu4(acc2[m]); wk[m] = ld4(w3k + ((size_t)m * 64 + lane) * 4); }

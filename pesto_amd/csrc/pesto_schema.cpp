@@ -188,6 +188,7 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
         }
         pad16(img);
         W.e_lds = (int32_t)img.size();
+        Mat Wk16(16, 64);
         {   // edge layer 2 frags: eq 2x2, ep 2x2, ev 4x4
             Mat Weq(32, 32), Wep(32, 32), Wev(64, 64);
             put_block(Weq, 0, 0, blob, L.eqkm.l[1], 0, 32);
@@ -207,6 +208,7 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
                 }
             }
             put_frags(img, Wk, 1, 4);
+            Wk16 = Wk;
             Mat Wv(64, 64);
             put_block(Wv, 0, 0, blob, L.evm.l[2], 0, 64);
             put_frags(img, Wv, 4, 4);               // [fo][m]
@@ -230,6 +232,17 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
             tmp.clear();
             put_frags_f16(tmp, Wv3, 4, 2);
             std::copy(tmp.begin(), tmp.end(), img.begin() + W.e_lds16 + EL_W3V);
+            // key networks: eq / ep layer 2 (K = 32: one k-group each) and the arranged key rows (K = 64: two k-groups)
+            Mat Weq2(32, 32), Wep2(32, 32);
+            put_block(Weq2, 0, 0, blob, L.eqkm.l[1], 0, 32);
+            put_block(Wep2, 0, 0, blob, L.epkm.l[1], 0, 32);
+            tmp.clear();
+            put_frags_f16(tmp, Weq2, 2, 1);             // 2 x 1 x 2 x 256 = 1024 floats (same as four fp32 fragments)
+            put_frags_f16(tmp, Wep2, 2, 1);
+            std::copy(tmp.begin(), tmp.end(), img.begin() + W.e_lds16 + EL_W2F);
+            tmp.clear();
+            put_frags_f16(tmp, Wk16, 1, 2);
+            std::copy(tmp.begin(), tmp.end(), img.begin() + W.e_lds16 + EL_W3K);
         }
         // node kernel: finish (qpm, ppm)
         {
