@@ -134,7 +134,7 @@ int run_forward(pesto_model* m, hipStream_t st, int64_t N, int64_t R, int k, con
             launch_node(st, m->W, l > 0 ? &m->img.layers[l - 1] : nullptr, &m->img.layers[l], N1, q[0], p[0], m->zrec.as<float>(),
                         m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->edge_variant);
             launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(),
-                        m->rec_cen.as<float>(), m->zrec.as<float>(), m->edge_blocks, m->edge_variant);
+                        m->rec_cen.as<float>(), p[0], m->zrec.as<float>(), m->edge_blocks, m->edge_variant);
         }
         launch_node(st, m->W, &m->img.layers[m->cfg.n_layers - 1], nullptr, N1, q[0], p[0], m->zrec.as<float>(), m->rec_nb.as<float>(),
                     m->rec_cen.as<float>(), m->edge_variant);
@@ -338,7 +338,7 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
     if (m->impl == 2) {
         const LayerW* L = &m->img.layers[layer];
         launch_node(st, m->W, nullptr, L, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->edge_variant);
-        launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->zrec.as<float>(), m->edge_blocks, m->edge_variant);
+        launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->edge_blocks, m->edge_variant);
         launch_node(st, m->W, L, nullptr, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->edge_variant);
         q_res = m->q_a.p; p_res = m->p_a.p;
     } else {

@@ -235,13 +235,8 @@ __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, Layer
         for (int fb = 0; fb < 2; ++fb) qq = mfma_block<2>(W + wp_.n_n2, 0, fb, lane, elu4(t[fb]), qq);
         if (valid) st4(cen + 512 + 4 * g, qq);
     }
-    // copy of p for the neighbours' vector-value gather
-    if (valid) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) st4(nb + 512 + c * 32 + 16 * m + 4 * g, p[c][m]);
-    }
+    // (p_j for the neighbours' vector-value gather is read from the state array itself: it is only rewritten by the
+    // NEXT node kernel, after this layer's edge kernel has finished)
 }
 
 // NM output blocks advanced through k-group kgp (two 16-feature input blocks) on v_mfma_f32_16x16x32_f16 with both
@@ -264,18 +259,31 @@ __device__ __forceinline__ void mfma16_multi(const float* __restrict__ wf, int m
     for (int m = 0; m < NM; ++m) acc[m] = MFMA16(wl[m], xh, acc[m]);
 }
 
-// node kernel on the f16-split MFMA path (same contract as k_node; 321 f16 MFMAs instead of 856 fp32 MFMAs per 16 atoms)
-__global__ __launch_bounds__(256) void k_node16(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
+// node kernel on the f16-split MFMA path (same contract as k_node; 321 f16 MFMAs instead of 856 fp32 MFMAs per 16 atoms).
+// Weight fragments are staged through LDS in three phases (finish: 24 KB, [U|A]: 64 KB, [G|C] + nqm: 46 KB) by all four
+// waves of the workgroup: a wave alone would wait an L2 round trip (~800 cycles) for every 12-MFMA group.
+constexpr int NODE_LDS_FLOATS = 16384;
+__device__ __forceinline__ void node_fill(float* lds, const float* __restrict__ src, int n_floats) {
+    __syncthreads();                                  // previous phase's readers are done
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(lds);
+    for (int k = threadIdx.x; k < n_floats / 4; k += 256) d4[k] = s4[k];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 2) void k_node16(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
                                                 int N1, float* __restrict__ q_state, float* __restrict__ p_state,
                                                 const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen) {
     const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
     const int n_tiles = (N1 + 15) >> 4, chunk = (n_tiles + 7) >> 3;
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int tile = xcd * chunk + jb * 4 + (threadIdx.x >> 6);
-    if (tile >= min(n_tiles, (xcd + 1) * chunk)) return;
+    __shared__ __attribute__((aligned(16))) float wl_[NODE_LDS_FLOATS];
+    const int tile_raw = xcd * chunk + jb * 4 + (threadIdx.x >> 6);
+    const bool live = tile_raw < min(n_tiles, (xcd + 1) * chunk);     // dead waves still help filling LDS
+    const int tile = live ? tile_raw : 0;
     const int i_raw = tile * 16 + e;
-    const bool valid = i_raw < N1;
-    const int i = valid ? i_raw : N1 - 1;
+    const bool valid = live && i_raw < N1;
+    const int i = (i_raw < N1) ? i_raw : N1 - 1;
 
     f32x4 q[2], p[3][2];
 #pragma unroll
@@ -286,6 +294,8 @@ __global__ __launch_bounds__(256) void k_node16(const float* __restrict__ W, Lay
     }
     f16x8 xh, xl;
     if (do_finish) {
+        node_fill(wl_, W + wf_.h_q0, 6144);            // [q0 | q1 | q2 | pp] f16 fragment tables, contiguous in the image
+        const float* Lq0 = wl_, *Lq1 = wl_ + 2048, *Lq2 = wl_ + 3072, *Lpp = wl_ + 4096;
         const float* zr = Z + (size_t)i * REC_Z;
         f32x4 h[2], t[2];
 #pragma unroll
@@ -293,16 +303,16 @@ __global__ __launch_bounds__(256) void k_node16(const float* __restrict__ W, Lay
 #pragma unroll
         for (int kgp = 0; kgp < 2; ++kgp) {
             split8(ld4(zr + 32 * kgp + 4 * g), ld4(zr + 32 * kgp + 16 + 4 * g), xh, xl);
-            mfma16_multi<2>(W + wf_.h_q0, 0, 2, kgp, lane, xh, xl, h);
+            mfma16_multi<2>(Lq0, 0, 2, kgp, lane, xh, xl, h);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) { h[m] = elu4(h[m]); t[m] = ld4(W + wf_.n_bq1 + 16 * m + 4 * g); }
         split8(h[0], h[1], xh, xl);
-        mfma16_multi<2>(W + wf_.h_q1, 0, 1, 0, lane, xh, xl, t);
+        mfma16_multi<2>(Lq1, 0, 1, 0, lane, xh, xl, t);
 #pragma unroll
         for (int m = 0; m < 2; ++m) { t[m] = elu4(t[m]); h[m] = ld4(W + wf_.n_bq2 + 16 * m + 4 * g); }
         split8(t[0], t[1], xh, xl);
-        mfma16_multi<2>(W + wf_.h_q2, 0, 1, 0, lane, xh, xl, h);
+        mfma16_multi<2>(Lq2, 0, 1, 0, lane, xh, xl, h);
 #pragma unroll
         for (int m = 0; m < 2; ++m) q[m] += h[m];
         {   // ppm: the three xyz components share each weight fragment (6 independent accumulators)
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(256) void k_node16(const float* __restrict__ W, Lay
                 f16x8 wh[2], wl[2], zh[3], zl[3];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const float* fr = W + wf_.h_pp + (size_t)((m * 2 + kgp) * 2) * 256 + lane * 4;
+                    const float* fr = Lpp + (size_t)((m * 2 + kgp) * 2) * 256 + lane * 4;
                     wh[m] = ld8h(fr); wl[m] = ld8h(fr + 256);
                 }
 #pragma unroll
@@ -351,6 +361,7 @@ __global__ __launch_bounds__(256) void k_node16(const float* __restrict__ W, Lay
     }
     if (!do_prep) return;
 
+    node_fill(wl_, W + wp_.h_ua, 16384);               // [U|A] fragments (64 KB)
     f32x4 pn[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(256) void k_node16(const float* __restrict__ W, Lay
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j] = ob < 8 ? ld4(W + wp_.n_b1 + 16 * (ob + j) + 4 * g) : f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<4>(W + wp_.h_ua, ob, 2, kgp, lane, xnh[kgp], xnl[kgp], a);
+        for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<4>(wl_, ob, 2, kgp, lane, xnh[kgp], xnl[kgp], a);
         if (valid) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -380,13 +391,17 @@ __global__ __launch_bounds__(256) void k_node16(const float* __restrict__ W, Lay
             }
         }
     }
+    node_fill(wl_, W + wp_.h_gc, 8192);                // [G|C] fragments (32 KB) ...
+    for (int k = threadIdx.x; k < 3584 / 4; k += 256)  // ... followed by the nqm tables [n0 | n1 | n2] (14 KB)
+        reinterpret_cast<f32x4*>(wl_ + 8192)[k] = reinterpret_cast<const f32x4*>(W + wp_.h_n0)[k];
+    __syncthreads();
 #pragma unroll 1
     for (int ob = 0; ob < 16; ob += 2) {
         f32x4 a[2][3];
         f16x8 wh[2], wl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float* fr = W + wp_.h_gc + (size_t)((ob + j) * 2) * 256 + lane * 4;
+            const float* fr = wl_ + (size_t)((ob + j) * 2) * 256 + lane * 4;
             wh[j] = ld8h(fr); wl[j] = ld8h(fr + 256);
 #pragma unroll
             for (int c = 0; c < 3; ++c) a[j][c] = f32x4{0, 0, 0, 0};
@@ -412,19 +427,13 @@ __global__ __launch_bounds__(256) void k_node16(const float* __restrict__ W, Lay
 #pragma unroll
         for (int m = 0; m < 2; ++m) { h[m] = ld4(W + wp_.n_bn0 + 16 * m + 4 * g); t[m] = ld4(W + wp_.n_bn1 + 16 * m + 4 * g); }
 #pragma unroll
-        for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<2>(W + wp_.h_n0, 0, 2, kgp, lane, xnh[kgp], xnl[kgp], h);
+        for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<2>(wl_ + 8192, 0, 2, kgp, lane, xnh[kgp], xnl[kgp], h);
         split8(elu4(h[0]), elu4(h[1]), xh, xl);
-        mfma16_multi<2>(W + wp_.h_n1, 0, 1, 0, lane, xh, xl, t);
+        mfma16_multi<2>(wl_ + 8192 + 2048, 0, 1, 0, lane, xh, xl, t);
         f32x4 qq[1] = {ld4(W + wp_.n_bn2 + 4 * g)};
         split8(elu4(t[0]), elu4(t[1]), xh, xl);
-        mfma16_multi<1>(W + wp_.h_n2, 0, 1, 0, lane, xh, xl, qq);
+        mfma16_multi<1>(wl_ + 8192 + 3072, 0, 1, 0, lane, xh, xl, qq);
         if (valid) st4(cen + 512 + 4 * g, qq[0]);
-    }
-    if (valid) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) st4(nb + 512 + c * 32 + 16 * m + 4 * g, p[c][m]);
     }
 }
 
@@ -512,7 +521,7 @@ template <int NN, int WPB, bool PF, bool F16>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
-                                                 float* __restrict__ Z, int stagger) {
+                                                 const float* __restrict__ p_state, float* __restrict__ Z, int stagger) {
     constexpr int A = 64 / NN;                 // centres per wave work item (64 edge rows)
     constexpr int TPC = NN >= 16 ? NN / 16 : 1;   // tiles per centre
     __shared__ EdgeSmem<WPB> sm;
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             f32x4 pv[4];
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
-                const float* pj = rec_nb + (size_t)ws.nb[16 * t + 2 * i2 + (esub & 1)] * REC_NB + 512 + 4 * quad;
+                const float* pj = p_state + (size_t)ws.nb[16 * t + 2 * i2 + (esub & 1)] * 96 + 4 * quad;
                 pv[i2] = esub < 2 ? ld4(pj) : f32x4{0, 0, 0, 0};
             }
             f32x4 h1[4];
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {   // second half of the tile's edges: these loads land during the MFMA phase
-                const float* pj = rec_nb + (size_t)ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)] * REC_NB + 512 + 4 * quad;
+                const float* pj = p_state + (size_t)ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)] * 96 + 4 * quad;
                 pv[i2] = esub < 2 ? ld4(pj) : f32x4{0, 0, 0, 0};
             }
             if (PF && t < 3) {   // second half of the next tile's first-layer operands: in flight during the value MFMAs
@@ -897,7 +906,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 const int i = c0 + a;
                 if (i < N1) {
                     const float* zb = ws.zbuf[sel];
-                    const float* pi = rec_nb + (size_t)i * REC_NB + 512;       // second block of Vp: p_i  (:133)
+                    const float* pi = p_state + (size_t)i * 96;                   // second block of Vp: p_i  (:133)
                     float* zo = Z + (size_t)i * REC_Z;
                     zo[lane] = zb[lane];
                     const int c = lane >> 5, s = lane & 31;
@@ -948,7 +957,7 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
 static int g_stagger = -1;
 template <int WPB, bool PF, bool F16>
 static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
-                          const float* rec_nb, const float* rec_cen, float* Z, int max_blocks) {
+                          const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks) {
     if (g_stagger < 0) { const char* e = getenv("PESTO_STAGGER"); g_stagger = e ? atoi(e) : 0; }
     const int A = 64 / lw.nn;
     const int n_work = (N1 + A - 1) / A;
@@ -957,18 +966,18 @@ static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int 
     if (blocks < 8) blocks = 8;
     const dim3 grid(blocks), block(WPB * 64);
     switch (lw.nn) {
-        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
-        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
-        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
-        default: hipLaunchKernelGGL((k_edge<64, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, Z, g_stagger); break;
+        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z, g_stagger); break;
+        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z, g_stagger); break;
+        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z, g_stagger); break;
+        default: hipLaunchKernelGGL((k_edge<64, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z, g_stagger); break;
     }
 }
 
 // variant 0 (default): value network on f16-split MFMA; variant 1: everything on exact fp32 MFMA
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
-                 const float* rec_nb, const float* rec_cen, float* Z, int max_blocks, int variant) {
-    if (variant == 1) launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, max_blocks);   // exact fp32 MFMA
-    else launch_edge_t<4, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, Z, max_blocks);                // f16-split value network
+                 const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant) {
+    if (variant == 1) launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);   // exact fp32 MFMA
+    else launch_edge_t<4, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);                // f16-split MFMA
 }
 
 }  // namespace pesto

@@ -58,7 +58,7 @@ constexpr int EL_WD = EL_B3V + 64;        // 128  (column 0 of edge layer 1: the
 constexpr int EDGE_LDS_FLOATS = EL_WD + 128;   // 11600
 
 // per-atom records written by the node kernel and read by the edge kernel (float counts)
-constexpr int REC_NB = 608;    // [fb 8][g 4][A,C0,C1,C2][r 4] = 512, then p[3][32]
+constexpr int REC_NB = 512;    // [fb 8][g 4][A,C0,C1,C2][r 4]  (p_j itself is gathered from the state array)
 constexpr int REC_CEN = 528;   // [fb 8][kg 4: G0,G1,G2,U][f 16] = 512, then Q[12] padded to 16
 constexpr int REC_Z = 256;     // Zq[h*32+s] (64), Zp[c][h*32+s] (192)
 struct ModelW {
