@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--config", default="i_v4_1")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency side measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--same-gpu", action="store_true",
+                    help="testing only: every rank uses GPU 0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="atom numbering of the synthetic clouds: generation order, or along a Z-order curve")
     args = ap.parse_args()
@@ -106,13 +109,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the forward pass)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu = 0 if args.same_gpu else local_rank
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     config = CONFIGS[args.config]
     n0 = config["em"]["N0"]
@@ -145,7 +152,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(z).all()
@@ -192,7 +199,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "ms_per_structure": elapsed / (args.steps * args.batch) * 1e3,
+            "ms_per_structure": elapsed / n_struct * 1e3,
             "ms_per_structure_batch1": lat_ms,
             "higher_is_better": True,
             "scaling": "weak",

@@ -437,6 +437,26 @@ __global__ __launch_bounds__(256, 2) void k_node16(const float* __restrict__ W, 
     }
 }
 
+// ---- cross-lane reductions on the VALU (DPP) instead of ds_bpermute round trips through the LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_bcast(float x, int src_lane) {   // src_lane must be wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+}
+// reduce over the 16 lanes of a DPP row (W16) or over each 8-lane half (!W16); every lane ends with the result
+template <bool W16, bool IS_MAX>
+__device__ __forceinline__ float row_reduce(float x) {
+#define PESTO_RR(ctrl) { const float y = dpp_mov<ctrl>(x); x = IS_MAX ? fmaxf(x, y) : x + y; }
+    PESTO_RR(0xB1)          // quad_perm [1,0,3,2]
+    PESTO_RR(0x4E)          // quad_perm [2,3,0,1]
+    PESTO_RR(0x141)         // row_half_mirror: i <-> 7-i
+    if (W16) PESTO_RR(0x140)   // row_mirror: i <-> 15-i
+#undef PESTO_RR
+    return x;
+}
+
 // =============================================================================================== edge kernel
 #ifdef PESTO_PROFILE_PHASES   // developer build: per-phase wave cycles (s_memtime), printed by pesto_destroy
 __device__ unsigned long long g_phase_cycles[8];
@@ -678,10 +698,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             if (TPC == 2) { const float m0 = fmaxf(mx[0], mx[1]), m1 = fmaxf(mx[2], mx[3]); mx[0] = mx[1] = m0; mx[2] = mx[3] = m1; }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float m = mx[t];
-                if (NN >= 16) m = fmaxf(m, __shfl_xor(m, 8));
-                m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 1));
-                const float v1 = __shfl(m, 16 + e), v2 = __shfl(m, 32 + e), v3 = __shfl(m, 48 + e);
+                const float m = row_reduce<(NN >= 16), true>(mx[t]);
+                // rows 1..3 (the three vector-key chunks) share one softmax: fetch their row results (wave-uniform lanes)
+                float v1, v2, v3;
+                if (NN >= 16) { v1 = lane_bcast(m, 16); v2 = lane_bcast(m, 32); v3 = lane_bcast(m, 48); }
+                else {
+                    v1 = e < 8 ? lane_bcast(m, 16) : lane_bcast(m, 24);
+                    v2 = e < 8 ? lane_bcast(m, 32) : lane_bcast(m, 40);
+                    v3 = e < 8 ? lane_bcast(m, 48) : lane_bcast(m, 56);
+                }
                 mx[t] = g == 0 ? m : fmaxf(v1, fmaxf(v2, v3));
                 ex[t] = __expf(lg[t][h] - mx[t]);
                 sr[t] = ex[t];
@@ -690,11 +715,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             if (TPC == 2) { const float s0 = sr[0] + sr[1], s1 = sr[2] + sr[3]; sr[0] = sr[1] = s0; sr[2] = sr[3] = s1; }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float s = sr[t];
-                if (NN >= 16) s += __shfl_xor(s, 8);
-                s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-                const float s1 = __shfl(s, 16 + e), s2 = __shfl(s, 32 + e), s3 = __shfl(s, 48 + e);
-                const float tot = g == 0 ? s : (s1 + s2) + s3;
+                const float sm_ = row_reduce<(NN >= 16), false>(sr[t]);
+                float s1, s2, s3;
+                if (NN >= 16) { s1 = lane_bcast(sm_, 16); s2 = lane_bcast(sm_, 32); s3 = lane_bcast(sm_, 48); }
+                else {
+                    s1 = e < 8 ? lane_bcast(sm_, 16) : lane_bcast(sm_, 24);
+                    s2 = e < 8 ? lane_bcast(sm_, 32) : lane_bcast(sm_, 40);
+                    s3 = e < 8 ? lane_bcast(sm_, 48) : lane_bcast(sm_, 56);
+                }
+                const float tot = g == 0 ? sm_ : (s1 + s2) + s3;
                 ws.wts[h * 4 + g][16 * t + e] = ex[t] / tot;
                 // centre-level sum of the part-2 weights (what multiplies p_i in Zp): written by the part-2 lanes
                 if (g == 2 && (NN == 8 ? (e & 7) == 0 : e == 0) && (t % TPC) == 0) {

@@ -166,3 +166,38 @@ def test_bad_inputs_raise():
     # the handle survives a failed structure (interfaceome/apply_model.py:57-82 skips and continues)
     z = m.forward_segments(g["X"], g["ids_topk"], onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
     assert np.abs(z - g["z"]).max() < 1e-4
+
+
+def test_forward_i_v3_0_synthetic_123_features():
+    """BASELINE config 3 shape: i_v3_0 (16 layers, 30+29+64 one-hots) on a synthetic cloud, real weights."""
+    from pesto_amd.topology import extract_topology, mask_to_segments, synthetic_structure
+    gs = golden("fwd_i_v3_0_synth512")
+    X, ids0, q, M = synthetic_structure(512, int(gs["seed"]), n0=123)
+    roa, R = mask_to_segments(M)
+    z = _model("i_v3_0").forward_segments(X, ids0 + 1, q, roa, R)
+    assert np.abs(z - gs["z"]).max() < 1e-4
+
+
+def test_large_structure_config5_vs_oracle():
+    """BASELINE config 5: one N=20,000-atom structure (R=2,500), i_v4_1 architecture; segmented pool, no dense [N,R] mask.
+    Checked against the CPU oracle on the same inputs (a few seconds on the GPU box's host cores)."""
+    from pesto_amd.topology import mask_to_segments, synthetic_structure
+    X, ids0, q, M = synthetic_structure(20000, 5)
+    roa, R = mask_to_segments(M)
+    assert R == 2500
+    ids = (ids0 + 1).astype(np.int32)
+    z = _model("i_v4_1").forward_segments(X, ids, q, roa, R)
+    assert z.shape == (2500, 5) and np.isfinite(z).all()
+    z_ref = _oracle("i_v4_1").forward_segments(X, ids, q, roa, R)
+    assert np.abs(z - z_ref).max() < 1e-4
+
+
+def test_determinism_bitwise():
+    """No float atomics anywhere: two runs of the same batch give identical bits (needed for 1-GPU == N-GPU results)."""
+    from pesto_amd.topology import mask_to_segments, synthetic_structure
+    X, ids0, q, M = synthetic_structure(700, 21)
+    roa, R = mask_to_segments(M)
+    m = _model("i_v4_1")
+    z0 = m.forward_segments(X, ids0 + 1, q, roa, R)
+    z1 = m.forward_segments(X, ids0 + 1, q, roa, R)
+    assert np.array_equal(z0, z1)
