@@ -31,6 +31,18 @@ def layer_flops_per_atom(nn):
     return 2.0 * (13696.0 + 36376.0 * nn)
 
 
+def executed_mfma_flops(config, n1):
+    """FLOPs the MFMA pipes actually execute per forward on the shipped path (f16 hi/lo split: 3 products per GEMM).
+    Edge kernel per 16-edge tile: 8 (16 when nn = 8) fp32 16x16x4 MFMAs (1,024 MAC) for the centre terms + 66 f16 16x16x32
+    MFMAs (8,192 MAC); node kernel per 16 atoms: 321 f16 MFMAs (the last launch only runs its 60-MFMA finish half)."""
+    total = 0.0
+    for l in config["sum"]:
+        tiles = n1 * l["nn"] / 16.0
+        total += tiles * ((16 if l["nn"] == 8 else 8) * 1024 + 66 * 8192) * 2.0
+        total += n1 / 16.0 * 321 * 8192 * 2.0
+    return total
+
+
 def layer_gather_bytes_per_atom(nn):
     """Gather-counted bytes per atom per layer (definition A): 1,024 + 532*n."""
     return 1024.0 + 532.0 * nn
@@ -173,6 +185,12 @@ def main():
     gbytes = sum(layer_gather_bytes_per_atom(l["nn"]) for l in config["sum"]) * n1
     achieved_tf = flops / (layers_ms * 1e-3) / 1e12
     achieved_gbs = gbytes / (layers_ms * 1e-3) / 1e9
+    # HBM-side bytes of the layer kernels from the committed PMC passes of this same command (profiles/pmc_collect.sh);
+    # only quoted when the workload matches the one the counters were collected on
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}_n{args.atoms}_b{args.batch}.json")
+    if os.path.exists(tpath) and args.order == "random":
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_forward")
 
     # ---- side measurement: batch-1 latency (ms per structure when structures arrive one at a time)
     lat_ms = None
@@ -213,9 +231,14 @@ def main():
                        "sharding": f"{world} rank(s), independent structures per rank, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "state-update layer kernels (all launches of one forward)",
                          "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / PEAK_F32_TFLOPS, "traffic": None,
+                         "frac": achieved_tf / PEAK_F32_TFLOPS, "traffic": traffic,
                          "flops_per_forward": flops, "launches": n_launch, "avg_launch_ms": layers_ms / n_launch,
-                         "layers_ms": layers_ms, "forward_ms": fwd_ms},
+                         "layers_ms": layers_ms, "forward_ms": fwd_ms,
+                         "executed_mfma_tflops": executed_mfma_flops(config, n1) / (layers_ms * 1e-3) / 1e12,
+                         "note": "achieved = reference-formulation FLOPs (SURVEY 8d) of all layer launches of one forward / their "
+                                 "HIP-event time; peak = dense fp32 MFMA. The kernels execute ~3x fewer FLOPs (first edge Linear "
+                                 "folded per atom) and run the big GEMMs as f16 hi/lo split MFMA, so frac can exceed 1; "
+                                 "traffic = HBM-side bytes per forward from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE)"},
             "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": achieved_gbs / PEAK_HBM_GBS, "bytes_per_forward": gbytes,
                              "note": "gather-counted algorithmic bytes (SURVEY 8d definition A) / layer-kernel time"},
