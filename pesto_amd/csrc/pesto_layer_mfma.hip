@@ -756,12 +756,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             // neighbours' p_j of this tile (third block of Vp, :134) as 16-byte gathers: lane = (esub = lane / 24, quad =
             // lane % 24) reads floats 4*quad..+3 of the 96-vector of edges 2i + esub; issued first, consumed after the
             // first-layer VALU work below
+            // (lanes 48..63 duplicate lanes 0..15's addresses; their sums are never read - no divergent branch around the loads)
             const int esub = lane / 24, quad = lane - 24 * esub;
             f32x4 pv[4];
+            {
+                int nbj[4];
 #pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {
-                const float* pj = p_state + (size_t)ws.nb[16 * t + 2 * i2 + (esub & 1)] * 96 + 4 * quad;
-                pv[i2] = esub < 2 ? ld4(pj) : f32x4{0, 0, 0, 0};
+                for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ws.nb[16 * t + 2 * i2 + (esub & 1)];
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
             }
             f32x4 h1[4];
 #pragma unroll
@@ -810,10 +813,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             }
             PHASE_MARK(3);
             __builtin_amdgcn_sched_barrier(0);
+            {   // second half of the tile's edges: these loads land during the MFMA phase
+                int nbj[4];
 #pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {   // second half of the tile's edges: these loads land during the MFMA phase
-                const float* pj = p_state + (size_t)ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)] * 96 + 4 * quad;
-                pv[i2] = esub < 2 ? ld4(pj) : f32x4{0, 0, 0, 0};
+                for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)];
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
             }
             if (PF && t < 3) {   // second half of the next tile's first-layer operands: in flight during the value MFMAs
 #pragma unroll
