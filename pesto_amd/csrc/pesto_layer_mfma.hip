@@ -472,7 +472,7 @@ __device__ unsigned long long g_phase_cycles[8];
 #endif
 struct EdgeWaveScratch {
     int nb[64];          // neighbour id per row
-    float geo[4][64];    // r_hat x, y, z and d per row (SoA)
+    float geo[5][64];    // r_hat x, y, z, d per row (SoA); row 4 = 1.0 (k = 3 slot of the centre MFMA's B operand)
     float wts[8][64];    // attention weights [h*4 + part][row]: part 0 scalar, 1..3 the vector chunks
     float wsum[8][2];    // per centre: sum over edges of the part-2 weights (multiplies p_i)
     float zbuf[2][256];  // Zq | Zp staging per centre (two centres per tile when NN == 8)
@@ -524,7 +524,7 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
     c.cenA = rec_cen + (size_t)min(c0 + aA, N1 - 1) * REC_CEN;
     c.cenB = rec_cen + (size_t)min(c0 + aA + 1, N1 - 1) * REC_CEN;
     c.rx = ws.geo[0][row]; c.ry = ws.geo[1][row]; c.rz = ws.geo[2][row]; c.d = ws.geo[3][row];
-    const float bg = g == 0 ? c.rx : (g == 1 ? c.ry : (g == 2 ? c.rz : 1.0f));
+    const float bg = ws.geo[g == 3 ? 4 : g][row];      // B operand of the centre MFMA: (r_x, r_y, r_z, 1)[k = g], one LDS read
     c.bgA = (NN == 8 && e >= 8) ? 0.0f : bg;
     c.bgB = (NN == 8 && e >= 8) ? bg : 0.0f;
 #ifdef PESTO_ABL_NOGATHER
@@ -576,9 +576,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         {   // rows of this work item: lane = row
             const int a = lane / NN, c = lane % NN, i = c0 + a;
             const bool valid = i < N1;
-            ws.nb[lane] = valid ? ids_s[(size_t)i * KMAX + c] : 0;
-            const float4 gg = valid ? geo[(size_t)i * KMAX + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            ws.geo[0][lane] = gg.x; ws.geo[1][lane] = gg.y; ws.geo[2][lane] = gg.z; ws.geo[3][lane] = gg.w;
+            const size_t src = (size_t)min(i, N1 - 1) * KMAX + c;           // unconditional loads, select afterwards
+            const int nbv = ids_s[src];
+            const float4 gg = geo[src];
+            ws.nb[lane] = valid ? nbv : 0;
+            ws.geo[0][lane] = valid ? gg.x : 0.f; ws.geo[1][lane] = valid ? gg.y : 0.f; ws.geo[2][lane] = valid ? gg.z : 0.f;
+            ws.geo[3][lane] = valid ? gg.w : 0.f; ws.geo[4][lane] = 1.0f;
         }
         __builtin_amdgcn_wave_barrier();
         PHASE_MARK(0);
