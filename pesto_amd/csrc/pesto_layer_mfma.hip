@@ -750,8 +750,17 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         L1Ops pre[4];
 #pragma unroll
         for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
+        float pi_pre[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // centre's own p_i (second block of Vp, :133), fetched a tile phase early
         for (int t = 0; t < 4; ++t) {
             const TileCtx tc = tcn;
+            if (t % TPC == 0) {
+#pragma unroll
+                for (int sel = 0; sel < (NN == 8 ? 2 : 1); ++sel) {
+                    const int ic = min(c0 + (NN == 8 ? 2 * t + sel : (16 * t) / NN), N1 - 1);
+                    pi_pre[sel][0] = p_state[(size_t)ic * 96 + lane];
+                    pi_pre[sel][1] = p_state[(size_t)ic * 96 + 64 + (lane & 31)];
+                }
+            }
             if (!PF && t > 0) {
 #pragma unroll
                 for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tc.cenA, tc.cenB, tc.recj);
@@ -943,16 +952,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 const int i = c0 + a;
                 if (i < N1) {
                     const float* zb = ws.zbuf[sel];
-                    const float* pi = p_state + (size_t)i * 96;                   // second block of Vp: p_i  (:133)
                     float* zo = Z + (size_t)i * REC_Z;
                     zo[lane] = zb[lane];
                     const int c = lane >> 5, s = lane & 31;
-                    const float pi0 = pi[lane];
+                    const float pi0 = pi_pre[sel][0];
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
                         zo[64 + c * 64 + h * 32 + s] = zb[64 + c * 64 + h * 32 + s] + ws.wsum[a][h] * pi0 + ws.z3buf[sel][h][lane];
                     if (lane < 32) {
-                        const float pi1 = pi[64 + lane];
+                        const float pi1 = pi_pre[sel][1];
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
                             zo[64 + 128 + h * 32 + lane] = zb[64 + 128 + h * 32 + lane] + ws.wsum[a][h] * pi1 + ws.z3buf[sel][h][64 + lane];
