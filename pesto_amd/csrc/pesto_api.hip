@@ -45,7 +45,7 @@ struct DevBuf {
         cap = want;
         return 0;
     }
-    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 }  // namespace
@@ -202,12 +202,12 @@ int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weight
 
 int pesto_destroy(pesto_model* m) {
     if (!m) return 0;
-    hipSetDevice(m->device);
+    (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     (void)hipDeviceSynchronize();
     debug_print_phase_cycles();
-    for (auto& e : m->ev) if (e) hipEventDestroy(e);
-    if (m->W) hipFree(m->W);
+    for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
+    if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
                       &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec})
         b->release();
@@ -364,15 +364,18 @@ int pesto_stage_pool(pesto_model* m, int64_t N, int64_t R, const float* q, const
     hipStream_t st = m->stream;
     int rc = 0;
     do {
-        if (hipMemsetAsync(m->flags.p, 0, 8, st) != hipSuccess) { rc = fail(PESTO_ERR_HIP, "memset failed"); break; }
-        hipMemcpyAsync(m->q_a.as<float>() + S, q, (size_t)N * S * 4, hipMemcpyHostToDevice, st);
-        hipMemcpyAsync(m->p_a.as<float>() + 96, p, (size_t)N * 96 * 4, hipMemcpyHostToDevice, st);
-        hipMemcpyAsync(m->in_roa.p, res_of_atom, (size_t)N * 4, hipMemcpyHostToDevice, st);
+        hipError_t he = hipMemsetAsync(m->flags.p, 0, 8, st);
+        auto also = [&he](hipError_t e) { if (he == hipSuccess) he = e; };
+        also(hipMemcpyAsync(m->q_a.as<float>() + S, q, (size_t)N * S * 4, hipMemcpyHostToDevice, st));
+        also(hipMemcpyAsync(m->p_a.as<float>() + 96, p, (size_t)N * 96 * 4, hipMemcpyHostToDevice, st));
+        also(hipMemcpyAsync(m->in_roa.p, res_of_atom, (size_t)N * 4, hipMemcpyHostToDevice, st));
         launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)N, (int)R, m->q_a.as<float>() + S, m->p_a.as<float>() + 96, m->in_roa.as<int>(),
                     m->pool_a.as<float>(), m->seg.as<int>(), m->seg.as<int>() + R, err_ptr(m), qr.as<float>(), pr.as<float>(), m->z.as<float>());
-        if (qr_out) hipMemcpyAsync(qr_out, qr.p, (size_t)R * S * 4, hipMemcpyDeviceToHost, st);
-        if (pr_out) hipMemcpyAsync(pr_out, pr.p, (size_t)R * 96 * 4, hipMemcpyDeviceToHost, st);
-        hipMemcpyAsync(z_out, m->z.p, (size_t)R * m->cfg.n_out * 4, hipMemcpyDeviceToHost, st);
+        also(hipGetLastError());
+        if (qr_out) also(hipMemcpyAsync(qr_out, qr.p, (size_t)R * S * 4, hipMemcpyDeviceToHost, st));
+        if (pr_out) also(hipMemcpyAsync(pr_out, pr.p, (size_t)R * 96 * 4, hipMemcpyDeviceToHost, st));
+        also(hipMemcpyAsync(z_out, m->z.p, (size_t)R * m->cfg.n_out * 4, hipMemcpyDeviceToHost, st));
+        if (he != hipSuccess) { rc = fail(PESTO_ERR_HIP, "stage_pool: %s", hipGetErrorString(he)); break; }
         rc = check_device_flag(m, st);
     } while (0);
     qr.release(); pr.release();

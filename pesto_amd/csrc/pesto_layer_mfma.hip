@@ -541,7 +541,7 @@ template <int NN, int WPB, bool PF, bool F16>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
-                                                 const float* __restrict__ p_state, float* __restrict__ Z, int stagger) {
+                                                 const float* __restrict__ p_state, float* __restrict__ Z) {
     constexpr int A = 64 / NN;                 // centres per wave work item (64 edge rows)
     constexpr int TPC = NN >= 16 ? NN / 16 : 1;   // tiles per centre
     __shared__ EdgeSmem<WPB> sm;
@@ -553,10 +553,6 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         for (int k = threadIdx.x; k < EDGE_LDS_FLOATS / 4; k += WPB * 64) dst[k] = src[k];
     }
     __syncthreads();
-    if (stagger > 0) {   // experiment: de-phase the two waves that share a SIMD (hardware wave slot parity)
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;   // HW_REG_HW_ID.wave_id
-        if (slot & 1) for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(32);
-    }
     EdgeWaveScratch& ws = sm.ws[wave];
     const float* w2f = sm.w + EL_W2F;
     const float* w3k = sm.w + EL_W3K;
@@ -999,11 +995,9 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
                        finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
 }
 
-static int g_stagger = -1;
 template <int WPB, bool PF, bool F16>
 static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                           const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks) {
-    if (g_stagger < 0) { const char* e = getenv("PESTO_STAGGER"); g_stagger = e ? atoi(e) : 0; }
     const int A = 64 / lw.nn;
     const int n_work = (N1 + A - 1) / A;
     int blocks = ((n_work + 7) / 8 + WPB - 1) / WPB * 8;   // per-XCD share of the work items, WPB per workgroup, x 8 XCDs
@@ -1011,10 +1005,10 @@ static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int 
     if (blocks < 8) blocks = 8;
     const dim3 grid(blocks), block(WPB * 64);
     switch (lw.nn) {
-        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z, g_stagger); break;
-        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z, g_stagger); break;
-        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z, g_stagger); break;
-        default: hipLaunchKernelGGL((k_edge<64, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z, g_stagger); break;
+        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
+        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
+        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
+        default: hipLaunchKernelGGL((k_edge<64, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
     }
 }
 
