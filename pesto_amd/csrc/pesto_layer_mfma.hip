@@ -537,6 +537,20 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
 
 // WPB = waves per workgroup: 4 (two workgroups per CU, 2 waves/SIMD, needs the explicit cross-tile prefetch PF)
 // or 12 / 16 (one workgroup per CU, 3 / 4 waves per SIMD sharing one LDS copy of the layer constants).
+// register-lean first layer of one tile (used when PF == false, i.e. with 3+ waves per SIMD hiding the gather latency):
+// blocks are fetched one ahead and consumed immediately instead of holding all four blocks' operands
+template <int NN>
+__device__ __forceinline__ void l1_tile_lean(int fb0, int lane, int g, const TileCtx& tc, const float* __restrict__ wd, f32x4* h1) {
+    L1Ops cur = l1_fetch<NN>(fb0, lane, g, tc.cenA, tc.cenB, tc.recj);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        L1Ops nxt = cur;
+        if (fb < 3) nxt = l1_fetch<NN>(fb0 + fb + 1, lane, g, tc.cenA, tc.cenB, tc.recj);
+        h1[fb] = l1_compute<NN>(cur, fb0 + fb, g, tc.bgA, tc.bgB, wd, tc.d, tc.rx, tc.ry, tc.rz);
+        cur = nxt;
+    }
+}
+
 template <int NN, int WPB, bool PF, bool F16>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
@@ -583,36 +597,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         PHASE_MARK(0);
 
         // ------------------------------------------------------------------ pass 1: keys -> logits (eqkm, epkm)
-        float lg[4][2];
         {
-            // tile-batched: the four first-layer blocks of a tile are computed together (VALU phase, independent
-            // chains), then the layer-2/3 MFMA chains run dense; the NEXT tile's gathers are issued in between
-            TileCtx tc[2];
-            tc[0] = tile_ctx<NN>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
-            L1Ops ops[2][4];
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) ops[0][fb] = l1_fetch<NN>(fb, lane, g, tc[0].cenA, tc[0].cenB, tc[0].recj);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const TileCtx& tcc = tc[t & 1];
-                if (!PF && t > 0) {
-#pragma unroll
-                    for (int fb = 0; fb < 4; ++fb) ops[t & 1][fb] = l1_fetch<NN>(fb, lane, g, tcc.cenA, tcc.cenB, tcc.recj);
-                }
-                f32x4 h1[4];
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb)
-                    h1[fb] = l1_compute<NN>(ops[t & 1][fb], fb, g, tcc.bgA, tcc.bgB, sm.w + EL_WD, tcc.d, tcc.rx, tcc.ry, tcc.rz);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t < 3) {
-                    tc[(t + 1) & 1] = tile_ctx<NN>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
-                    const TileCtx& tn = tc[(t + 1) & 1];
-                    if (PF) {
-#pragma unroll
-                        for (int fb = 0; fb < 4; ++fb) ops[(t + 1) & 1][fb] = l1_fetch<NN>(fb, lane, g, tn.cenA, tn.cenB, tn.recj);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            // layers 2/3 of the key networks for one tile, raw logits parked in the (not yet used) attention-weight table
+            auto keys_of_tile = [&](int t, const f32x4* h1) {
                 f32x4 acc2[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc2[m] = ld4(sm.w + EL_B2 + 16 * m + 4 * g);
@@ -682,9 +669,46 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 const float* Qv = rec_cen + (size_t)min(c0 + aMine, N1 - 1) * REC_CEN + 512 + (g == 0 ? 0 : 6);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    lg[t][h] = (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) / sdk;
+                    ws.wts[h * 4 + g][16 * t + e] = (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) / sdk;
+            };
+            if (PF) {
+                // tile-batched: the four first-layer blocks of a tile are computed together (VALU phase, independent
+                // chains), then the layer-2/3 MFMA chains run dense; the NEXT tile's gathers are issued in between
+                TileCtx tc[2];
+                tc[0] = tile_ctx<NN>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
+                L1Ops ops[2][4];
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb) ops[0][fb] = l1_fetch<NN>(fb, lane, g, tc[0].cenA, tc[0].cenB, tc[0].recj);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const TileCtx& tcc = tc[t & 1];
+                    f32x4 h1[4];
+#pragma unroll
+                    for (int fb = 0; fb < 4; ++fb)
+                        h1[fb] = l1_compute<NN>(ops[t & 1][fb], fb, g, tcc.bgA, tcc.bgB, sm.w + EL_WD, tcc.d, tcc.rx, tcc.ry, tcc.rz);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t < 3) {
+                        tc[(t + 1) & 1] = tile_ctx<NN>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
+                        const TileCtx& tn = tc[(t + 1) & 1];
+#pragma unroll
+                        for (int fb = 0; fb < 4; ++fb) ops[(t + 1) & 1][fb] = l1_fetch<NN>(fb, lane, g, tn.cenA, tn.cenB, tn.recj);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    keys_of_tile(t, h1);
+                }
+            } else {
+#pragma unroll 1
+                for (int t = 0; t < 4; ++t) {   // register-lean: rolled loop, operands fetched block by block
+                    const TileCtx tcc = tile_ctx<NN>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
+                    f32x4 h1[4];
+                    l1_tile_lean<NN>(0, lane, g, tcc, sm.w + EL_WD, h1);
+                    keys_of_tile(t, h1);
+                }
             }
         }
+        float lg[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { lg[t][0] = ws.wts[g][16 * t + e]; lg[t][1] = ws.wts[4 + g][16 * t + e]; }
         PHASE_MARK(1);
         // ------------------------------------------------------------------ softmax per centre  (:139-140)
         // scalar: over the NN rows of part 0; vector: over the 3*NN slots of parts 1..3 together
@@ -744,11 +768,13 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 
         TileCtx tcn = tile_ctx<NN>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
         L1Ops pre[4];
+        if (PF) {
 #pragma unroll
-        for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
+            for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
+        }
         float pi_pre[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // centre's own p_i (second block of Vp, :133), fetched a tile phase early
         for (int t = 0; t < 4; ++t) {
-            const TileCtx tc = tcn;
+            const TileCtx tc = PF ? tcn : tile_ctx<NN>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
             if (t % TPC == 0) {
 #pragma unroll
                 for (int sel = 0; sel < (NN == 8 ? 2 : 1); ++sel) {
@@ -756,10 +782,6 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     pi_pre[sel][0] = p_state[(size_t)ic * 96 + lane];
                     pi_pre[sel][1] = p_state[(size_t)ic * 96 + 64 + (lane & 31)];
                 }
-            }
-            if (!PF && t > 0) {
-#pragma unroll
-                for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tc.cenA, tc.cenB, tc.recj);
             }
             // neighbours' p_j of this tile (third block of Vp, :134) as 16-byte gathers: lane = (esub = lane / 24, quad =
             // lane % 24) reads floats 4*quad..+3 of the 96-vector of edges 2i + esub; issued first, consumed after the
@@ -775,9 +797,13 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
             }
             f32x4 h1[4];
+            if (PF) {
 #pragma unroll
-            for (int fbl = 0; fbl < 4; ++fbl)
-                h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
+                for (int fbl = 0; fbl < 4; ++fbl)
+                    h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
+            } else {
+                l1_tile_lean<NN>(4, lane, g, tc, sm.w + EL_WD, h1);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
@@ -786,7 +812,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2];
             }
             // the first-layer operands of the NEXT tile fly during this tile's MFMA phase
-            if (t < 3) {
+            if (PF && t < 3) {
                 tcn = tile_ctx<NN>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
                 if (PF) {
 #pragma unroll
@@ -802,18 +828,22 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 for (int kgp = 0; kgp < 2; ++kgp) {
                     f16x8 xh, xl;
                     split8(h1[2 * kgp], h1[2 * kgp + 1], xh, xl);
-                    f16x8 wh[4], wl[4];
+                    constexpr int G = PF ? 4 : 2;      // output blocks per fragment batch (2 keeps the lean build under 168 VGPRs)
 #pragma unroll
-                    for (int ml = 0; ml < 4; ++ml) {
-                        const float* fr = w2f + 8 * 256 + (size_t)((ml * 2 + kgp) * 2) * 256 + lane * 4;
-                        wh[ml] = ld8h(fr); wl[ml] = ld8h(fr + 256);
+                    for (int m0 = 0; m0 < 4; m0 += G) {
+                        f16x8 wh[G], wl[G];
+#pragma unroll
+                        for (int ml = 0; ml < G; ++ml) {
+                            const float* fr = w2f + 8 * 256 + (size_t)(((m0 + ml) * 2 + kgp) * 2) * 256 + lane * 4;
+                            wh[ml] = ld8h(fr); wl[ml] = ld8h(fr + 256);
+                        }
+#pragma unroll
+                        for (int ml = 0; ml < G; ++ml) acc2[m0 + ml] = MFMA16(wh[ml], xh, acc2[m0 + ml]);
+#pragma unroll
+                        for (int ml = 0; ml < G; ++ml) acc2[m0 + ml] = MFMA16(wh[ml], xl, acc2[m0 + ml]);
+#pragma unroll
+                        for (int ml = 0; ml < G; ++ml) acc2[m0 + ml] = MFMA16(wl[ml], xh, acc2[m0 + ml]);
                     }
-#pragma unroll
-                    for (int ml = 0; ml < 4; ++ml) acc2[ml] = MFMA16(wh[ml], xh, acc2[ml]);
-#pragma unroll
-                    for (int ml = 0; ml < 4; ++ml) acc2[ml] = MFMA16(wh[ml], xl, acc2[ml]);
-#pragma unroll
-                    for (int ml = 0; ml < 4; ++ml) acc2[ml] = MFMA16(wl[ml], xh, acc2[ml]);
                 }
             } else {
 #pragma unroll
@@ -848,18 +878,22 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 for (int kgp = 0; kgp < 2; ++kgp) {
                     f16x8 ah, al;
                     split8(h2[2 * kgp], h2[2 * kgp + 1], ah, al);
-                    f16x8 bh[4], bl[4];
+                    constexpr int G = PF ? 4 : 2;
 #pragma unroll
-                    for (int fo = 0; fo < 4; ++fo) {
-                        const float* fr = w3v + (size_t)((fo * 2 + kgp) * 2) * 256 + lane * 4;
-                        bh[fo] = ld8h(fr); bl[fo] = ld8h(fr + 256);
+                    for (int f0 = 0; f0 < 4; f0 += G) {
+                        f16x8 bh[G], bl[G];
+#pragma unroll
+                        for (int fo = 0; fo < G; ++fo) {
+                            const float* fr = w3v + (size_t)(((f0 + fo) * 2 + kgp) * 2) * 256 + lane * 4;
+                            bh[fo] = ld8h(fr); bl[fo] = ld8h(fr + 256);
+                        }
+#pragma unroll
+                        for (int fo = 0; fo < G; ++fo) v[f0 + fo] = MFMA16(ah, bh[fo], v[f0 + fo]);
+#pragma unroll
+                        for (int fo = 0; fo < G; ++fo) v[f0 + fo] = MFMA16(al, bh[fo], v[f0 + fo]);
+#pragma unroll
+                        for (int fo = 0; fo < G; ++fo) v[f0 + fo] = MFMA16(ah, bl[fo], v[f0 + fo]);
                     }
-#pragma unroll
-                    for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA16(ah, bh[fo], v[fo]);
-#pragma unroll
-                    for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA16(al, bh[fo], v[fo]);
-#pragma unroll
-                    for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA16(ah, bl[fo], v[fo]);
                 }
             } else {
 #pragma unroll
@@ -1012,11 +1046,16 @@ static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int 
     }
 }
 
-// variant 0 (default): value network on f16-split MFMA; variant 1: everything on exact fp32 MFMA
+// variant 0 (default): 12 waves per workgroup (3 per SIMD, one workgroup per CU), register-lean first layer, f16-split MFMA
+// variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch)
+// variants 2-4 (experiments kept for A/B runs): 4-wave workgroups with prefetch; 4-wave lean; 16-wave lean
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant) {
-    if (variant == 1) launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);   // exact fp32 MFMA
-    else launch_edge_t<4, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);                // f16-split MFMA
+    if (variant == 1) launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+    else if (variant == 2) launch_edge_t<4, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+    else if (variant == 3) launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+    else if (variant == 4) launch_edge_t<16, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
+    else launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
 }
 
 }  // namespace pesto
