@@ -1055,7 +1055,13 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
     else if (variant == 2) launch_edge_t<4, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
     else if (variant == 3) launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
     else if (variant == 4) launch_edge_t<16, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
-    else launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
+    else {
+        // small launches (one structure, or the nn = 8/16 layers of a small batch) cannot fill 256 twelve-wave workgroups:
+        // the same kernel body in four-wave workgroups spreads them over more CUs
+        const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
+        if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
+        else launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+    }
 }
 
 }  // namespace pesto
