@@ -86,6 +86,14 @@ int pesto_synchronize(pesto_model* m);
 int pesto_set_timing(pesto_model* m, int32_t enabled);
 int pesto_get_timing(pesto_model* m, double* layers_ms, double* total_ms, int32_t* n_layer_launches);
 
+/* replaces: extract_topology (src/data_encoding.py:87-102) + the index half of collate_batch_features (src/dataset.py:100-109)
+ * for a concatenated batch: exact k nearest neighbours per atom WITHIN its structure, ascending distance, entries with
+ * D < 1e-2 (self, coincident atoms) last, emitted as 1-based batch-global ids zero-padded to 64 columns.
+ * X [n_total,3] and ids_out [n_total,64] follow ptr_kind; struct_offsets [n_struct+1] is a HOST array (offsets[0] = 0,
+ * offsets[n_struct] = n_total). */
+int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
+                      void* ids_out, int32_t ids_kind, int32_t ptr_kind, void* stream);
+
 /* ---- per-stage entry points (HOST pointers), used by tests/ to pin each stage against the oracle ----
  * replaces: em.forward (model/model.py:34) */
 int pesto_stage_embed(pesto_model* m, int64_t N, const float* q0, float* q_out /*[N,32]*/);

@@ -63,6 +63,7 @@ struct pesto_model {
     int edge_blocks = 512;                 // persistent workgroups of the edge kernel (2 per CU)
     int edge_variant = 0;                  // PESTO_EDGE_VARIANT: 0 = 4 waves/WG + prefetch, 1 = 12 waves/WG, 2 = 16 waves/WG
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
+    DevBuf knn_off;                       // structure offsets of the last pesto_knn_collate call
     // state left by pesto_stage_unpack for pesto_stage_layer
     int64_t stage_N = -1;
     // timing
@@ -209,7 +210,7 @@ int pesto_destroy(pesto_model* m) {
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
-                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec})
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off})
         b->release();
     delete m;
     return 0;
@@ -278,6 +279,38 @@ int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k, const float* 
         return rc;
     HIP_TRY(hipMemcpyAsync(z_out, m->z.p, (size_t)R * m->cfg.n_out * 4, hipMemcpyDeviceToHost, st));
     return check_device_flag(m, st);   // synchronises
+}
+
+int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
+                      void* ids_out, int32_t ids_kind, int32_t ptr_kind, void* stream) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (n_total < 1 || n_total > 0x7ffffff0 / 96 || n_struct < 1 || !struct_offsets || !X || !ids_out || k < 1 || k > KMAX)
+        return fail(PESTO_ERR_INVALID, "bad arguments");
+    if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
+    if (struct_offsets[0] != 0 || struct_offsets[n_struct] != n_total) return fail(PESTO_ERR_INVALID, "struct_offsets must span [0, n_total]");
+    for (int s = 0; s < n_struct; ++s)
+        if (struct_offsets[s + 1] <= struct_offsets[s]) return fail(PESTO_ERR_INVALID, "empty or unordered structure %d", s);
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
+    if (m->knn_off.ensure((size_t)(n_struct + 1) * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    if (ptr_kind == PESTO_PTR_DEVICE) {
+        hipStream_t st = (hipStream_t)stream;
+        HIP_TRY(hipMemcpyAsync(m->knn_off.p, struct_offsets, (size_t)(n_struct + 1) * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));     // the offsets array is the caller's host memory: finish the copy before returning
+        launch_knn_collate(st, (int)n_total, n_struct, m->knn_off.as<int>(), X, k, ids_out, ids_kind);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if (ptr_kind != PESTO_PTR_HOST) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    if (m->in_X.ensure((size_t)n_total * 12) || m->in_ids.ensure((size_t)n_total * KMAX * id_sz)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    HIP_TRY(hipMemcpyAsync(m->knn_off.p, struct_offsets, (size_t)(n_struct + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->in_X.p, X, (size_t)n_total * 12, hipMemcpyHostToDevice, st));
+    launch_knn_collate(st, (int)n_total, n_struct, m->knn_off.as<int>(), m->in_X.as<float>(), k, m->in_ids.p, ids_kind);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ids_out, m->in_ids.p, (size_t)n_total * KMAX * id_sz, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
 }
 
 // ------------------------------------------------------------------ per-stage entry points (host pointers)

@@ -16,6 +16,7 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
                  const float* Z, float* rec_nb, float* rec_cen, int variant);
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant);
+void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, void* ids_out, int ids_kind);
 void debug_print_phase_cycles();   // no-op unless built with -DPESTO_PROFILE_PHASES
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,
                  const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out);

@@ -506,4 +506,75 @@ void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, in
     hipLaunchKernelGGL(k_pool_reduce, dim3(R), dim3(64), 0, st, W, mw, n_out, R, q, p, a_tmp, roa, lo, hi, qr_out, pr_out, z_out);
 }
 
+
+// ------------------------------------------------------------------------------------------------ k-NN topology + collate
+// replaces extract_topology (src/data_encoding.py:87-102, dense [N,N,3] on the host) and the index part of
+// collate_batch_features (src/dataset.py:100-109) with one kernel over a concatenated batch.
+// Contract reproduced exactly: D = |X_j - X_i| in fp32 (products and sums rounded separately, like torch.norm over a
+// 3-vector), entries with D < 1e-2 (self, coincident atoms) are pushed behind every other atom of the structure - the
+// reference adds max(D) to them, so they sort after all unmasked entries and by D among themselves - and the
+// min(k, N_s) smallest keys are emitted in ascending order as 1-based batch-global ids, zero padded to KMAX columns.
+// One wave per query atom: candidates stream through in chunks of 64 (one per lane); the running k best are kept one
+// per lane, sorted across the wave; a chunk that cannot improve the current worst is rejected with one ballot, the
+// others are bitonic-sorted and merged (64-bit keys: [masked | distance bits | index], so ties break by index).
+__device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// one compare-exchange stage of a bitonic network across the wave: partner = lane ^ j, ascending if `up`
+__device__ __forceinline__ unsigned long long bitonic_step(unsigned long long v, int lane, int j, bool up) {
+    const unsigned long long o = shfl_xor64(v, j);
+    const bool lower = (lane & j) == 0;
+    const bool take_min = lower == up;
+    return take_min ? (v < o ? v : o) : (v < o ? o : v);
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void k_knn_collate(int n_total, int n_struct, const int* __restrict__ offsets,
+                                                     const float* __restrict__ X, int k, IdT* __restrict__ ids_out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_total) return;
+    // structure of atom i: binary search in offsets (wave-uniform)
+    int lo = 0, hi = n_struct;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
+    const int s0 = offsets[lo], s1 = offsets[lo + 1];
+    const float xi = X[3 * (size_t)i], yi = X[3 * (size_t)i + 1], zi = X[3 * (size_t)i + 2];
+    const unsigned long long WORST = ~0ull;
+    unsigned long long top = WORST;                 // lane l holds the (l+1)-th best key so far, ascending across lanes
+    for (int base = s0; base < s1; base += 64) {
+        const int j = base + lane;
+        unsigned long long key = WORST;
+        if (j < s1) {
+            const float rx = X[3 * (size_t)j] - xi, ry = X[3 * (size_t)j + 1] - yi, rz = X[3 * (size_t)j + 2] - zi;
+            const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz)));
+            const unsigned masked = d < 1e-2f ? 1u : 0u;
+            key = ((unsigned long long)((masked << 31) | __float_as_uint(d)) << 32) | (unsigned)(j - s0);   // d >= 0: bit 31 is free
+        }
+        const unsigned long long worst = ((unsigned long long)__shfl((unsigned)(top >> 32), 63) << 32) | __shfl((unsigned)top, 63);
+        if (__ballot(key < worst) == 0ull) continue;        // nothing in this chunk beats the current k-th best
+        // sort the chunk ascending (bitonic sort over 64 lanes)
+        for (int size = 2; size <= 64; size <<= 1)
+            for (int jj = size >> 1; jj > 0; jj >>= 1) key = bitonic_step(key, lane, jj, (lane & size) == 0 || size == 64);
+        // 64 smallest of (top ascending, chunk ascending): min(top[l], chunk[63-l]) is bitonic; merge it ascending
+        const unsigned long long rev = shfl_xor64(key, 63);
+        unsigned long long m = top < rev ? top : rev;
+        for (int jj = 32; jj > 0; jj >>= 1) m = bitonic_step(m, lane, jj, true);
+        top = m;
+    }
+    // lanes 0..knn-1 hold the neighbours in ascending order; zero padding beyond (dataset.py:100,109)
+    const int knn = min(k, s1 - s0);
+    long long id = 0;
+    if (lane < knn) id = (long long)(unsigned)(top & 0xffffffffu) + s0 + 1;
+    if (lane < KMAX) ids_out[(size_t)i * KMAX + lane] = (IdT)id;
+}
+
+void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, void* ids_out, int ids_kind) {
+    const dim3 grid((n_total + 3) / 4), block(256);
+    if (ids_kind == PESTO_IDS_INT64)
+        hipLaunchKernelGGL(k_knn_collate<long long>, grid, block, 0, st, n_total, n_struct, offsets, X, k, (long long*)ids_out);
+    else
+        hipLaunchKernelGGL(k_knn_collate<int>, grid, block, 0, st, n_total, n_struct, offsets, X, k, (int*)ids_out);
+}
+
 }  // namespace pesto

@@ -186,6 +186,40 @@ class Model:
         if tuple(rs) != (N,):
             raise ValueError(f"residue mask must cover N={N} atoms, got {tuple(rs)}")
 
+    # ------------------------------------------------------------------ k-NN topology + collate on the GPU
+    def knn_collate(self, X, sizes, k=64):
+        """ids_topk [sum(sizes), 64] for a concatenated batch: what ``extract_topology(X_s, 64)[0]`` per structure followed by
+        ``collate_batch_features`` produce on the host in the reference (src/data_encoding.py:87-102, src/dataset.py:100-109):
+        exact k nearest neighbours within each structure, ascending distance, D < 1e-2 entries last, 1-based batch-global ids,
+        0 = padding. X: [sum(sizes), 3] float32 (ROCm tensor -> int64 ROCm tensor on the current stream; CPU tensor / numpy -> same kind)."""
+        h = self._ensure()
+        lib = _lib.load()
+        sizes = [int(v) for v in sizes]
+        offs = np.zeros(len(sizes) + 1, dtype=np.int32)
+        offs[1:] = np.cumsum(sizes)
+        n = int(offs[-1])
+        if _is_torch(X) and X.is_cuda:
+            import torch
+            Xc = X.detach().to(torch.float32).contiguous()
+            if tuple(Xc.shape) != (n, 3):
+                raise ValueError(f"X must be [{n},3], got {tuple(Xc.shape)}")
+            ids = torch.empty((n, 64), dtype=torch.int64, device=X.device)
+            stream = torch.cuda.current_stream(X.device).cuda_stream
+            _lib.check(lib.pesto_knn_collate(h, n, len(sizes), offs.ctypes.data, Xc.data_ptr(), k, ids.data_ptr(), _lib.IDS_INT64,
+                                             _lib.PTR_DEVICE, stream))
+            return ids
+        as_torch = _is_torch(X)
+        Xn = np.ascontiguousarray(X.detach().numpy() if as_torch else X, dtype=np.float32)
+        if Xn.shape != (n, 3):
+            raise ValueError(f"X must be [{n},3], got {Xn.shape}")
+        ids = np.empty((n, 64), dtype=np.int64)
+        _lib.check(lib.pesto_knn_collate(h, n, len(sizes), offs.ctypes.data, Xn.ctypes.data, k, ids.ctypes.data, _lib.IDS_INT64,
+                                         _lib.PTR_HOST, None))
+        if as_torch:
+            import torch
+            return torch.from_numpy(ids)
+        return ids
+
     # ------------------------------------------------------------------ per-stage access (tests)
     def stage_embed(self, q0):
         q0 = np.ascontiguousarray(q0, np.float32)

@@ -201,3 +201,73 @@ def test_determinism_bitwise():
     z0 = m.forward_segments(X, ids0 + 1, q, roa, R)
     z1 = m.forward_segments(X, ids0 + 1, q, roa, R)
     assert np.array_equal(z0, z1)
+
+
+# ------------------------------------------------------------------ GPU k-NN topology + collate
+def _check_same_neighbours(ids, ref, X, offset=0):
+    """Exact match, or - where the reference's sort keys tie - the same keys in the same order. Keys follow the reference
+    rule D + max(D) * (D < 1e-2) (src/data_encoding.py:93): e.g. self (key = max(D)) ties with the farthest atom of the
+    structure, and torch.topk / argsort may legitimately keep either one."""
+    if np.array_equal(ids, ref):
+        return
+    assert np.array_equal((ids > 0), (ref > 0))
+    D = np.sqrt(((X[None, :, :] - X[:, None, :]) ** 2).sum(2, dtype=np.float32)).astype(np.float32)
+    K = D + D.max() * (D < 1e-2)
+    rows = np.arange(X.shape[0])[:, None]
+    k_a = np.where(ids > 0, K[rows, np.maximum(ids - 1 - offset, 0)], 0)
+    k_b = np.where(ref > 0, K[rows, np.maximum(ref - 1 - offset, 0)], 0)
+    assert np.allclose(k_a, k_b, rtol=0, atol=2e-6)
+    assert np.mean(ids != ref) < 0.01
+
+
+def test_knn_matches_reference_extract_topology():
+    m = _model("i_v4_0")
+    g = golden("topology_synth300")
+    ids = m.knn_collate(g["X"], [300])
+    assert ids.shape == (300, 64) and ids.dtype == np.int64
+    assert np.array_equal(ids, g["ids_topk0"].astype(np.int64) + 1)
+    g = golden("topology_synth50")                           # N < 64: knn = N, self sorted to the far end, zero padding
+    ids = m.knn_collate(g["X"], [50])
+    assert np.all(ids[:, 50:] == 0) and np.all(ids[:, :50] > 0)
+    assert np.array_equal(ids[:, :48], g["ids_topk0"][:, :48].astype(np.int64) + 1)
+    assert np.array_equal(np.sort(ids[:, :50], 1), np.sort(g["ids_topk0"].astype(np.int64) + 1, 1))
+
+
+def test_knn_collate_matches_reference_batch_fixture():
+    g = golden("edge_batch2")                               # reference extract_topology + collate_batch_features on 300 + 40 atoms
+    (n0, r0), (n1, r1) = g["sizes"]
+    m = _model("i_v4_0")
+    ids = m.knn_collate(g["X"], [n0, n1])
+    ref = g["ids_topk"].astype(np.int64)
+    assert np.array_equal(ids[:n0], ref[:n0])
+    assert np.array_equal(ids[n0:, :n1 - 2], ref[n0:, :n1 - 2]) and np.all(ids[n0:, n1:] == 0)
+    assert np.array_equal(np.sort(ids[n0:], 1), np.sort(ref[n0:], 1))
+
+
+def test_knn_ragged_batch_with_coincident_atoms_vs_host_contract():
+    from pesto_amd.topology import collate_batch_features, extract_topology, synthetic_cloud
+    sizes = [65, 700, 64, 33, 1200]
+    Xs = [synthetic_cloud(n, 40 + k) for k, n in enumerate(sizes)]
+    Xs[1][17] = Xs[1][400]                                   # exactly coincident pair
+    Xs[4][5] = Xs[4][900] + np.float32(2e-3)                 # within the 1e-2 mask
+    batch = [[x, extract_topology(x, 64), np.zeros((x.shape[0], 30), np.float32), np.ones((x.shape[0], 1), bool)] for x in Xs]
+    Xc, ref, _, _ = collate_batch_features(batch)
+    m = _model("i_v4_0")
+    ids = m.knn_collate(Xc, sizes)
+    off = 0
+    for n in sizes:
+        _check_same_neighbours(ids[off:off + n], ref[off:off + n], Xc[off:off + n], offset=off)
+        off += n
+    import torch
+    ids_dev = m.to("cuda:0").knn_collate(torch.from_numpy(Xc).cuda(), sizes)
+    assert ids_dev.is_cuda and torch.equal(ids_dev.cpu(), torch.from_numpy(ids))
+
+
+def test_knn_feeds_forward_end_to_end():
+    """kNN on the GPU -> forward on the GPU gives the reference golden z (inputs: coordinates only, no host topology)."""
+    g = golden("fwd_i_v4_0_2CUA")
+    m = _model("i_v4_0")
+    ids = m.knn_collate(g["X"], [g["X"].shape[0]])
+    roa = g["res_of_atom"]
+    z = m.forward_segments(g["X"], ids, onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
+    assert np.abs(z - g["z"]).max() < 1e-4
