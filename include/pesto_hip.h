@@ -75,6 +75,18 @@ int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k,
                   const float* q0, const int32_t* res_of_atom,
                   float* z_out, int32_t ptr_kind, void* stream);
 
+/* replaces: the per-frame loop of the reference's MD analysis (md_analysis/apply_model_md.ipynb cell 6):
+ *     for i in frames: z_i = model(X_traj[:, i], ids_topk, q, M)        # ids_topk, q, M of frame 0 for every frame
+ * n_frames coordinate sets of the SAME N atoms share ids_topk [N,k], q0 [N,n0] and res_of_atom [N]; frame f's atom i is at
+ * X + f*x_frame_stride + i*x_atom_stride (strides in floats, xyz contiguous; the reference's [N, frames, 3] trajectory
+ * tensor is x_frame_stride = 3, x_atom_stride = 3*frames). z_out is [n_frames, R, n_out]. Results are those of n_frames
+ * separate pesto_forward calls (per-frame max(D) and wrap-around, src/model_operations.py:8-12), but frames_per_launch
+ * frames (0 = choose: about 32k atoms) run as ONE batch through every kernel. Pointer/stream rules as pesto_forward. */
+int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_frames,
+                         const float* X, int64_t x_frame_stride, int64_t x_atom_stride,
+                         const void* ids_topk, int32_t ids_kind, const float* q0, const int32_t* res_of_atom,
+                         float* z_out, int32_t frames_per_launch, int32_t ptr_kind, void* stream);
+
 /* bytes of device workspace a batch of (N, R) needs (ownership: SURVEY 8b) */
 int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* bytes);
 
@@ -93,6 +105,14 @@ int pesto_get_timing(pesto_model* m, double* layers_ms, double* total_ms, int32_
  * offsets[n_struct] = n_total). */
 int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
                       void* ids_out, int32_t ids_kind, int32_t ptr_kind, void* stream);
+
+/* replaces: the caller-side post-op p = sigmoid(z) (apply_model.ipynb:160, interfaceome/apply_model.py:76) and the
+ * residue -> atom expansion of encode_bfactor (src/structure.py:208-218) for per-residue predictions.
+ * z [R,n_out] -> p_out [R,n_out] (may be NULL) and bfactor_out [n_out,N] channel-major (may be NULL):
+ * bfactor_out[c][i] = sigmoid(z[res_of_atom[i]][c]). With device pointers the call is asynchronous on `stream`, so a bulk
+ * loop can keep every structure's result on the GPU and copy back once. */
+int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, const int32_t* res_of_atom, float* p_out, float* bfactor_out,
+                      int32_t ptr_kind, void* stream);
 
 /* ---- per-stage entry points (HOST pointers), used by tests/ to pin each stage against the oracle ----
  * replaces: em.forward (model/model.py:34) */

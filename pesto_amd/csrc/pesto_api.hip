@@ -64,6 +64,8 @@ struct pesto_model {
     int edge_variant = 0;                  // PESTO_EDGE_VARIANT: 0 = 4 waves/WG + prefetch, 1 = 12 waves/WG, 2 = 16 waves/WG
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     DevBuf knn_off;                       // structure offsets of the last pesto_knn_collate call
+    DevBuf dmax, roa_f;                   // per-frame max(D) words; residue column per atom of a frame batch
+    std::vector<float> pack;              // host packing buffer for strided host frames
     // state left by pesto_stage_unpack for pesto_stage_layer
     int64_t stage_N = -1;
     // timing
@@ -102,8 +104,8 @@ int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
     return rc ? fail(PESTO_ERR_NOMEM, "device workspace allocation failed for N=%lld R=%lld", (long long)N, (long long)R) : 0;
 }
 
-// flags buffer layout: [0] dmax bits (unsigned), [1] error flag (int)
-unsigned* dmax_ptr(pesto_model* m) { return m->flags.as<unsigned>(); }
+// flags buffer layout: [1] error flag (int); per-frame max(D) bit patterns live in m->dmax
+unsigned* dmax_ptr(pesto_model* m) { return m->dmax.as<unsigned>(); }
 int* err_ptr(pesto_model* m) { return m->flags.as<int>() + 1; }
 
 int check_device_flag(pesto_model* m, hipStream_t st) {
@@ -115,18 +117,41 @@ int check_device_flag(pesto_model* m, hipStream_t st) {
     return 0;
 }
 
-// the launch sequence of Model.forward (model/model.py:32-52) on stream st; all pointers are device pointers
-int run_forward(pesto_model* m, hipStream_t st, int64_t N, int64_t R, int k, const float* X, const void* ids, int ids_kind,
-                const float* q0, const int* roa, float* z_out, float* qr_out, float* pr_out) {
-    const int N1 = (int)N + 1;
+// one launch sequence = F coordinate frames of N atoms / R residues sharing ids, q0 and the residue map (F = 1: the plain
+// collated batch of Model.forward). All pointers are device pointers; X strides are in floats.
+struct FwdArgs {
+    int64_t N = 0, R = 0, F = 1;
+    int k = 0;
+    const float* X = nullptr;
+    int64_t xs_frame = 0, xs_atom = 3;
+    const void* ids = nullptr;
+    int ids_kind = PESTO_IDS_INT64;
+    const float* q0 = nullptr;
+    const int* roa = nullptr;
+    float* z_out = nullptr;     // [F*R, n_out]
+};
+
+// the launch sequence of Model.forward (model/model.py:32-52) on stream st
+int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a) {
+    const int64_t NT = a.N * a.F, RT = a.R * a.F;
+    const int N1 = (int)NT + 1;
     float* q[2] = {m->q_a.as<float>(), m->q_b.as<float>()};
     float* p[2] = {m->p_a.as<float>(), m->p_b.as<float>()};
+    if (m->dmax.ensure((size_t)a.F * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    const int* roa = a.roa;
+    if (a.F > 1) {
+        if (m->roa_f.ensure((size_t)NT * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+        roa = m->roa_f.as<int>();
+    }
     HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(m->dmax.p, 0, (size_t)a.F * 4, st));
     HIP_TRY(hipMemsetAsync(q[0], 0, S * sizeof(float), st));                       // sink row of q (model_operations.py:17)
     HIP_TRY(hipMemsetAsync(p[0], 0, (size_t)N1 * 96 * sizeof(float), st));         // p0 = zeros (model.py:37)
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[0], st));
-    launch_embed(st, m->W, m->img.model.em, (int)N, m->cfg.n0, q0, q[0]);
-    launch_unpack(st, (int)N, k, X, ids, ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(), dmax_ptr(m), err_ptr(m));
+    launch_embed(st, m->W, m->img.model.em, (int)NT, (int)a.N, m->cfg.n0, a.q0, q[0]);
+    launch_unpack(st, (int)a.N, (int)a.F, a.k, a.X, a.xs_frame, a.xs_atom, a.ids, a.ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(),
+                  dmax_ptr(m), err_ptr(m));
+    if (a.F > 1) launch_expand_roa(st, (int)a.N, (int)a.R, (int)a.F, a.roa, m->roa_f.as<int>(), err_ptr(m));
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[1], st));
     int cur = 0;
     if (m->impl == 2) {
@@ -150,8 +175,8 @@ int run_forward(pesto_model* m, hipStream_t st, int64_t N, int64_t R, int k, con
         m->n_layer_launches = m->impl == 2 ? 2 * m->cfg.n_layers + 1 : m->cfg.n_layers;
         m->have_timing = true;
     }
-    launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)N, (int)R, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
-                m->seg.as<int>(), m->seg.as<int>() + R, err_ptr(m), qr_out, pr_out, z_out);
+    launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)NT, (int)RT, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
+                m->seg.as<int>(), m->seg.as<int>() + RT, err_ptr(m), nullptr, nullptr, a.z_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -210,7 +235,7 @@ int pesto_destroy(pesto_model* m) {
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
-                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off})
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f})
         b->release();
     delete m;
     return 0;
@@ -253,32 +278,78 @@ int pesto_get_timing(pesto_model* m, double* layers_ms, double* total_ms, int32_
 
 int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k, const float* X, const void* ids_topk, int32_t ids_kind,
                   const float* q0, const int32_t* res_of_atom, float* z_out, int32_t ptr_kind, void* stream) {
+    return pesto_forward_frames(m, N, R, k, 1, X, 3 * N, 3, ids_topk, ids_kind, q0, res_of_atom, z_out, 1, ptr_kind, stream);
+}
+
+int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_frames, const float* X, int64_t x_frame_stride,
+                         int64_t x_atom_stride, const void* ids_topk, int32_t ids_kind, const float* q0, const int32_t* res_of_atom,
+                         float* z_out, int32_t frames_per_launch, int32_t ptr_kind, void* stream) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || R > N) return fail(PESTO_ERR_INVALID, "bad sizes N=%lld R=%lld", (long long)N, (long long)R);
+    if (n_frames < 1) return fail(PESTO_ERR_INVALID, "n_frames=%lld must be >= 1", (long long)n_frames);
     if (k < 1 || k > KMAX) return fail(PESTO_ERR_INVALID, "k=%d must be in 1..%d", k, KMAX);
     for (int l = 0; l < m->cfg.n_layers; ++l)
         if (m->cfg.nn[l] > KMAX) return fail(PESTO_ERR_INVALID, "layer nn exceeds %d", KMAX);
     if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
     if (!X || !ids_topk || !q0 || !res_of_atom || !z_out) return fail(PESTO_ERR_INVALID, "null buffer");
+    if (ptr_kind != PESTO_PTR_HOST && ptr_kind != PESTO_PTR_DEVICE) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
+    if (x_atom_stride < 3 && N > 1) return fail(PESTO_ERR_INVALID, "x_atom_stride must be >= 3 floats");
+    // frames per launch: ~24k atoms fill the chip (measured: 8 x 3,000 beats 16 x 3,000 - at 5.6 KB of records and state
+    // per atom, 24k atoms = 134 MB still sit in the 256 MB Infinity Cache); chunks are balanced over the frame count
+    int64_t fpl = frames_per_launch > 0 ? frames_per_launch : (24576 + N / 2) / N;
+    if (fpl < 1) fpl = 1;
+    if (fpl > n_frames) fpl = n_frames;
+    if (fpl * N > 0x7ffffff0 / 96) fpl = (0x7ffffff0 / 96) / N;
+    const int64_t n_chunks = (n_frames + fpl - 1) / fpl;
+    fpl = (n_frames + n_chunks - 1) / n_chunks;
     HIP_TRY(hipSetDevice(m->device));
-    if (int rc = ensure_workspace(m, N, R)) return rc;
+    if (int rc = ensure_workspace(m, N * fpl, R * fpl)) return rc;
     const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
-    if (ptr_kind == PESTO_PTR_DEVICE)   // stream is taken literally: NULL is HIP's default (null) stream
-        return run_forward(m, (hipStream_t)stream, N, R, k, X, ids_topk, ids_kind, q0, res_of_atom, z_out, nullptr, nullptr);
+    const int n_out = m->cfg.n_out;
+    FwdArgs a;
+    a.N = N; a.R = R; a.k = k; a.ids_kind = ids_kind;
+    if (ptr_kind == PESTO_PTR_DEVICE) {   // stream is taken literally: NULL is HIP's default (null) stream
+        a.ids = ids_topk; a.q0 = q0; a.roa = res_of_atom; a.xs_frame = x_frame_stride; a.xs_atom = x_atom_stride;
+        for (int64_t c = 0; c < n_chunks; ++c) {
+            const int64_t f0 = c * n_frames / n_chunks;
+            a.F = (c + 1) * n_frames / n_chunks - f0;
+            a.X = X + f0 * x_frame_stride;
+            a.z_out = z_out + f0 * R * n_out;
+            if (int rc = run_forward(m, (hipStream_t)stream, a)) return rc;
+        }
+        return 0;
+    }
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
-    if (ptr_kind != PESTO_PTR_HOST) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
-    if (m->in_X.ensure((size_t)N * 3 * 4) || m->in_ids.ensure((size_t)N * k * id_sz) || m->in_q0.ensure((size_t)N * m->cfg.n0 * 4) ||
+    if (m->in_X.ensure((size_t)N * fpl * 3 * 4) || m->in_ids.ensure((size_t)N * k * id_sz) || m->in_q0.ensure((size_t)N * m->cfg.n0 * 4) ||
         m->in_roa.ensure((size_t)N * 4))
         return fail(PESTO_ERR_NOMEM, "staging allocation failed");
-    HIP_TRY(hipMemcpyAsync(m->in_X.p, X, (size_t)N * 3 * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->in_ids.p, ids_topk, (size_t)N * k * id_sz, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->in_q0.p, q0, (size_t)N * m->cfg.n0 * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->in_roa.p, res_of_atom, (size_t)N * 4, hipMemcpyHostToDevice, st));
-    if (int rc = run_forward(m, st, N, R, k, m->in_X.as<float>(), m->in_ids.p, ids_kind, m->in_q0.as<float>(), m->in_roa.as<int>(),
-                             m->z.as<float>(), nullptr, nullptr))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(z_out, m->z.p, (size_t)R * m->cfg.n_out * 4, hipMemcpyDeviceToHost, st));
-    return check_device_flag(m, st);   // synchronises
+    a.ids = m->in_ids.p; a.q0 = m->in_q0.as<float>(); a.roa = m->in_roa.as<int>();
+    a.X = m->in_X.as<float>(); a.xs_frame = 3 * N; a.xs_atom = 3;
+    a.z_out = m->z.as<float>();
+    const bool packed = x_atom_stride == 3 && (x_frame_stride == 3 * N || n_frames == 1);
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t f0 = c * n_frames / n_chunks;
+        a.F = (c + 1) * n_frames / n_chunks - f0;
+        const float* src = X + f0 * x_frame_stride;
+        if (!packed) {   // gather the strided host frames (e.g. the reference's [N, frames, 3] trajectory tensor) into [F, N, 3]
+            m->pack.resize((size_t)a.F * N * 3);
+            for (int64_t f = 0; f < a.F; ++f)
+                for (int64_t i = 0; i < N; ++i) {
+                    const float* x = src + f * x_frame_stride + i * x_atom_stride;
+                    float* d = m->pack.data() + ((size_t)f * N + i) * 3;
+                    d[0] = x[0]; d[1] = x[1]; d[2] = x[2];
+                }
+            src = m->pack.data();
+        }
+        HIP_TRY(hipMemcpyAsync(m->in_X.p, src, (size_t)a.F * N * 3 * 4, hipMemcpyHostToDevice, st));
+        if (int rc = run_forward(m, st, a)) return rc;
+        HIP_TRY(hipMemcpyAsync(z_out + f0 * R * n_out, m->z.p, (size_t)a.F * R * n_out * 4, hipMemcpyDeviceToHost, st));
+        if (int rc = check_device_flag(m, st)) return rc;   // synchronises: staging buffers are free for the next chunk
+    }
+    return 0;
 }
 
 int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
@@ -313,6 +384,43 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
     return 0;
 }
 
+int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, const int32_t* res_of_atom, float* p_out, float* bfactor_out,
+                      int32_t ptr_kind, void* stream) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || !z || (!p_out && !bfactor_out) || (bfactor_out && !res_of_atom)) return fail(PESTO_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(m->device));
+    const int n_out = m->cfg.n_out;
+    if (m->flags.ensure(64)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    if (ptr_kind == PESTO_PTR_DEVICE) {
+        // no flag reset / read-back here: the call stays asynchronous; a bad res_of_atom entry is clamped to residue 0
+        launch_postprocess((hipStream_t)stream, (int)N, (int)R, n_out, z, res_of_atom, p_out, bfactor_out, err_ptr(m));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if (ptr_kind != PESTO_PTR_HOST) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    DevBuf out;
+    if (m->z.ensure((size_t)R * 32 * 4) || m->in_roa.ensure((size_t)N * 4) || out.ensure(((size_t)R + N) * n_out * 4))
+        return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    float* dp = out.as<float>();
+    float* db = dp + (size_t)R * n_out;
+    int rc = 0;
+    do {
+        hipError_t he = hipMemsetAsync(m->flags.p, 0, 8, st);
+        auto also = [&he](hipError_t e) { if (he == hipSuccess) he = e; };
+        also(hipMemcpyAsync(m->z.p, z, (size_t)R * n_out * 4, hipMemcpyHostToDevice, st));
+        if (bfactor_out) also(hipMemcpyAsync(m->in_roa.p, res_of_atom, (size_t)N * 4, hipMemcpyHostToDevice, st));
+        launch_postprocess(st, (int)N, (int)R, n_out, m->z.as<float>(), m->in_roa.as<int>(), dp, bfactor_out ? db : nullptr, err_ptr(m));
+        also(hipGetLastError());
+        if (p_out) also(hipMemcpyAsync(p_out, dp, (size_t)R * n_out * 4, hipMemcpyDeviceToHost, st));
+        if (bfactor_out) also(hipMemcpyAsync(bfactor_out, db, (size_t)N * n_out * 4, hipMemcpyDeviceToHost, st));
+        if (he != hipSuccess) { rc = fail(PESTO_ERR_HIP, "postprocess: %s", hipGetErrorString(he)); break; }
+        rc = check_device_flag(m, st);
+    } while (0);
+    out.release();
+    return rc;
+}
+
 // ------------------------------------------------------------------ per-stage entry points (host pointers)
 int pesto_stage_embed(pesto_model* m, int64_t N, const float* q0, float* q_out) {
     if (check_model(m)) return PESTO_ERR_INVALID;
@@ -322,7 +430,7 @@ int pesto_stage_embed(pesto_model* m, int64_t N, const float* q0, float* q_out) 
     if (m->in_q0.ensure((size_t)N * m->cfg.n0 * 4)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
     hipStream_t st = m->stream;
     HIP_TRY(hipMemcpyAsync(m->in_q0.p, q0, (size_t)N * m->cfg.n0 * 4, hipMemcpyHostToDevice, st));
-    launch_embed(st, m->W, m->img.model.em, (int)N, m->cfg.n0, m->in_q0.as<float>(), m->q_a.as<float>());
+    launch_embed(st, m->W, m->img.model.em, (int)N, (int)N, m->cfg.n0, m->in_q0.as<float>(), m->q_a.as<float>());
     HIP_TRY(hipMemcpyAsync(q_out, m->q_a.as<float>() + S, (size_t)N * S * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     m->stage_N = -1;
@@ -339,10 +447,13 @@ int pesto_stage_unpack(pesto_model* m, int64_t N, int32_t k, const float* X, con
     const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
     if (m->in_X.ensure((size_t)N * 3 * 4) || m->in_ids.ensure((size_t)N * k * id_sz)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
     hipStream_t st = m->stream;
+    if (m->dmax.ensure(4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
     HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(m->dmax.p, 0, 4, st));
     HIP_TRY(hipMemcpyAsync(m->in_X.p, X, (size_t)N * 3 * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->in_ids.p, ids_topk, (size_t)N * k * id_sz, hipMemcpyHostToDevice, st));
-    launch_unpack(st, (int)N, k, m->in_X.as<float>(), m->in_ids.p, ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(), dmax_ptr(m), err_ptr(m));
+    launch_unpack(st, (int)N, 1, k, m->in_X.as<float>(), 3 * N, 3, m->in_ids.p, ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(), dmax_ptr(m),
+                  err_ptr(m));
     if (int rc = check_device_flag(m, st)) return rc;
     m->stage_N = N;
     if (D_out || R_out) {

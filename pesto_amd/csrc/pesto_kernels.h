@@ -6,9 +6,13 @@
 
 namespace pesto {
 
-void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int n0, const float* q0, float* q_state);
-void launch_unpack(hipStream_t st, int N, int k, const float* X, const void* ids, int ids_kind, int* ids_s, float4* geo,
-                   unsigned* dmax_bits, int* err_flag);
+// N atoms in the batch; q0 has nq rows used with period nq (nq = N, or the frame length of a trajectory batch)
+void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state);
+// F coordinate frames of Nf atoms sharing one ids table [Nf,k] (F = 1: a plain collated batch); X strides in floats;
+// dmax_bits[F] must be zeroed
+void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
+                   int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag);
+void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int* roa_f, int* err_flag);
 void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                      const float* q_in, const float* p_in, float* q_out, float* p_out);
 // MFMA layer (pesto_layer_mfma.hip): per-atom node kernel (finish previous layer / prepare records) + edge kernel
@@ -17,6 +21,7 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant);
 void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, void* ids_out, int ids_kind);
+void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z, const int* roa, float* p_out, float* bf_out, int* err_flag);
 void debug_print_phase_cycles();   // no-op unless built with -DPESTO_PROFILE_PHASES
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,
                  const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out);

@@ -26,13 +26,13 @@ __device__ __forceinline__ float g32_linear(const float* __restrict__ W, const L
 
 // ------------------------------------------------------------------------------------------------ embedding
 // q[i+1][:] = em(q0[i][:]) ; 8 atoms per 256-thread block, 32 lanes per atom.  model/model.py:34
-__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW em, int N, int n0,
+__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW em, int N, int nq, int n0,
                                                const float* __restrict__ q0, float* __restrict__ q_state) {
     __shared__ float xs[8][512];
     __shared__ float hs[8][64];
     const int g = threadIdx.x >> 5, s = threadIdx.x & 31;
     const int i = blockIdx.x * 8 + g;
-    const int ic = i < N ? i : N - 1;
+    const int ic = (i < N ? i : N - 1) % nq;   // nq < N: frames of a trajectory share one q0 (row i of every frame)
     for (int k = s; k < n0; k += 32) xs[g][k] = q0[(size_t)ic * n0 + k];
     __syncthreads();
     float v = g32_linear(W, em.l[0], xs[g], s);
@@ -50,23 +50,31 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW
 // ------------------------------------------------------------------------------------------------ geometry
 // pass 1: R = X[ids-1] - X[i] (ids-1 = -1 wraps to the last atom), D = |R|, block max -> atomic max of the
 // float bit pattern (D >= 0). Output rows are shifted by the sink row.   src/model_operations.py:8-10
+// Frames (blockIdx.y): F independent coordinate sets of Nf atoms sharing ONE ids table (the MD use of the reference,
+// md_analysis/apply_model_md.ipynb cell 6: model(X_frame, ids_topk_of_frame0, q, M) per frame). Frame f becomes atoms
+// f*Nf+1 .. (f+1)*Nf of the internal batch; the wrap target and the max are per frame, exactly as in F separate calls.
 template <typename IdT>
-__global__ __launch_bounds__(256) void k_unpack1(int N, int k, const float* __restrict__ X, const IdT* __restrict__ ids,
-                                                 int* __restrict__ ids_s, float4* __restrict__ geo,
+__global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __restrict__ X, int64_t xs_frame, int64_t xs_atom,
+                                                 const IdT* __restrict__ ids, int* __restrict__ ids_s, float4* __restrict__ geo,
                                                  unsigned* __restrict__ dmax_bits, int* __restrict__ err_flag) {
     float d = 0.0f;
+    const int f = blockIdx.y;
+    const float* Xf = X + (int64_t)f * xs_frame;
+    const int64_t a0 = (int64_t)f * Nf;
     // 4 slots per thread (grid-stride by the grid size) keeps the number of blocks, hence atomics, at a quarter
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)N * KMAX; e += (int64_t)gridDim.x * 256) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)Nf * KMAX; e += (int64_t)gridDim.x * 256) {
         const int i = (int)(e >> 6), c = (int)(e & 63);
         long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
-        if (id < 0 || id > N) { atomicOr(err_flag, 1); id = 0; }
+        if (id < 0 || id > Nf) { atomicOr(err_flag, 1); id = 0; }
         long long j = id - 1;
-        if (j < 0) j += N;
-        const float rx = X[3 * j] - X[3 * i], ry = X[3 * j + 1] - X[3 * i + 1], rz = X[3 * j + 2] - X[3 * i + 2];
+        if (j < 0) j += Nf;
+        const float* xj = Xf + j * xs_atom;
+        const float* xi = Xf + (int64_t)i * xs_atom;
+        const float rx = xj[0] - xi[0], ry = xj[1] - xi[1], rz = xj[2] - xi[2];
         const float dd = sqrtf(rx * rx + ry * ry + rz * rz);
         d = fmaxf(d, dd);
-        ids_s[(size_t)(i + 1) * KMAX + c] = (int)id;
-        geo[(size_t)(i + 1) * KMAX + c] = make_float4(rx, ry, rz, dd);
+        ids_s[(size_t)(a0 + i + 1) * KMAX + c] = id ? (int)(id + a0) : 0;
+        geo[(size_t)(a0 + i + 1) * KMAX + c] = make_float4(rx, ry, rz, dd);
     }
     // wave max -> block max -> ONE atomic per block (a single word saturates at ~90 atomics/us: one per wave
     // cost 277 us at 24k atoms)
@@ -76,20 +84,31 @@ __global__ __launch_bounds__(256) void k_unpack1(int N, int k, const float* __re
     __syncthreads();
     if (threadIdx.x == 0) {
         const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (m > 0.0f) atomicMax(dmax_bits, __float_as_uint(m));
+        if (m > 0.0f) atomicMax(dmax_bits + f, __float_as_uint(m));
     }
 }
 
 // pass 2: D += max(D) * (D < 1e-2);  R /= D.  Also writes the sink row 0.   src/model_operations.py:12-20
-__global__ __launch_bounds__(256) void k_unpack2(int N, int* __restrict__ ids_s, float4* __restrict__ geo,
+__global__ __launch_bounds__(256) void k_unpack2(int N, int Nf, int* __restrict__ ids_s, float4* __restrict__ geo,
                                                  const unsigned* __restrict__ dmax_bits) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over (N+1) * 64 slots
     if (e >= (int64_t)(N + 1) * KMAX) return;
     if (e < KMAX) { ids_s[e] = 0; geo[e] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
-    const float dmax = __uint_as_float(*dmax_bits);
+    const float dmax = __uint_as_float(dmax_bits[((e >> 6) - 1) / Nf]);
     float4 g = geo[e];
     const float d = g.w + dmax * (g.w < 1e-2f ? 1.0f : 0.0f);
     geo[e] = make_float4(g.x / d, g.y / d, g.z / d, d);
+}
+
+// residue column of every atom of an F-frame batch: roa_f[f*Nf + i] = roa[i] + f*R
+__global__ __launch_bounds__(256) void k_expand_roa(int Nf, int R, int F, const int* __restrict__ roa, int* __restrict__ roa_f,
+                                                    int* __restrict__ err_flag) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)Nf * F) return;
+    const int f = (int)(e / Nf), i = (int)(e % Nf);
+    int r = roa[i];
+    if (r < 0 || r >= R) { atomicOr(err_flag, 2); r = 0; }
+    roa_f[e] = r + f * R;
 }
 
 // ------------------------------------------------------------------------------------------------ layer v1
@@ -483,19 +502,25 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int n0, const float* q0, float* q_state) {
-    hipLaunchKernelGGL(k_embed, dim3((N + 7) / 8), dim3(256), 0, st, W, em, N, n0, q0, q_state);
+void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state) {
+    hipLaunchKernelGGL(k_embed, dim3((N + 7) / 8), dim3(256), 0, st, W, em, N, nq, n0, q0, q_state);
 }
 
-void launch_unpack(hipStream_t st, int N, int k, const float* X, const void* ids, int ids_kind, int* ids_s, float4* geo,
-                   unsigned* dmax_bits, int* err_flag) {
-    const int64_t n1 = (int64_t)N * KMAX;
-    const dim3 grid1((unsigned)((n1 + 1023) / 1024)), grid2((unsigned)((n1 + KMAX + 255) / 256));
+void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
+                   int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag) {
+    const int64_t n1 = (int64_t)Nf * KMAX, nall = (int64_t)Nf * F * KMAX;
+    const dim3 grid1((unsigned)((n1 + 1023) / 1024), (unsigned)F), grid2((unsigned)((nall + KMAX + 255) / 256));
     if (ids_kind == PESTO_IDS_INT64)
-        hipLaunchKernelGGL(k_unpack1<long long>, grid1, dim3(256), 0, st, N, k, X, (const long long*)ids, ids_s, geo, dmax_bits, err_flag);
+        hipLaunchKernelGGL(k_unpack1<long long>, grid1, dim3(256), 0, st, Nf, k, X, xs_frame, xs_atom, (const long long*)ids, ids_s, geo,
+                           dmax_bits, err_flag);
     else
-        hipLaunchKernelGGL(k_unpack1<int>, grid1, dim3(256), 0, st, N, k, X, (const int*)ids, ids_s, geo, dmax_bits, err_flag);
-    hipLaunchKernelGGL(k_unpack2, grid2, dim3(256), 0, st, N, ids_s, geo, dmax_bits);
+        hipLaunchKernelGGL(k_unpack1<int>, grid1, dim3(256), 0, st, Nf, k, X, xs_frame, xs_atom, (const int*)ids, ids_s, geo, dmax_bits,
+                           err_flag);
+    hipLaunchKernelGGL(k_unpack2, grid2, dim3(256), 0, st, Nf * F, Nf, ids_s, geo, dmax_bits);
+}
+
+void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int* roa_f, int* err_flag) {
+    hipLaunchKernelGGL(k_expand_roa, dim3((unsigned)(((int64_t)Nf * F + 255) / 256)), dim3(256), 0, st, Nf, R, F, roa, roa_f, err_flag);
 }
 
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,
@@ -567,6 +592,30 @@ __global__ __launch_bounds__(256) void k_knn_collate(int n_total, int n_struct, 
     long long id = 0;
     if (lane < knn) id = (long long)(unsigned)(top & 0xffffffffu) + s0 + 1;
     if (lane < KMAX) ids_out[(size_t)i * KMAX + lane] = (IdT)id;
+}
+
+// ------------------------------------------------------------------------------------------------ post-processing
+// p = sigmoid(z) per residue (apply_model.ipynb:160, interfaceome/apply_model.py:76) and its expansion to
+// atoms, bf[c][i] = p[res_of_atom[i]][c] - what encode_bfactor (src/structure.py:208-218) does on the host with one
+// numpy mask per residue. One thread per output element; z is tiny, so the atom part recomputes the sigmoid.
+__global__ __launch_bounds__(256) void k_postprocess(int N, int R, int n_out, const float* __restrict__ z, const int* __restrict__ roa,
+                                                     float* __restrict__ p_out, float* __restrict__ bf_out, int* __restrict__ err_flag) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n_res = (int64_t)R * n_out;
+    if (e < n_res) {
+        if (p_out) p_out[e] = 1.0f / (1.0f + expf(-z[e]));
+    } else if (bf_out && e < n_res + (int64_t)N * n_out) {
+        const int64_t a = e - n_res;
+        const int c = (int)(a / N), i = (int)(a % N);
+        int r = roa[i];
+        if (r < 0 || r >= R) { atomicOr(err_flag, 2); r = 0; }
+        bf_out[a] = 1.0f / (1.0f + expf(-z[(size_t)r * n_out + c]));
+    }
+}
+
+void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z, const int* roa, float* p_out, float* bf_out, int* err_flag) {
+    const int64_t n = (int64_t)R * n_out + (bf_out ? (int64_t)N * n_out : 0);
+    hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, N, R, n_out, z, roa, p_out, bf_out, err_flag);
 }
 
 void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, void* ids_out, int ids_kind) {

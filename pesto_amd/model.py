@@ -186,6 +186,128 @@ class Model:
         if tuple(rs) != (N,):
             raise ValueError(f"residue mask must cover N={N} atoms, got {tuple(rs)}")
 
+    # ------------------------------------------------------------------ trajectory frames
+    def forward_frames(self, X_frames, ids_topk, q0, M, frame_axis=0, frames_per_launch=0):
+        """z [F, R, N2] for F coordinate frames of the same atoms with ONE topology: what the reference's MD loop
+        ``for i in frames: z_i = model(X_traj[:, i], ids_topk, q, M)`` (md_analysis/apply_model_md.ipynb cell 6) computes, with
+        several frames per kernel launch. ``X_frames``: [F, N, 3] (frame_axis=0) or the reference's [N, F, 3] trajectory
+        tensor (frame_axis=1); strided views are read in place (no copy). Other arguments as forward()."""
+        if self.validate:
+            roa, R = mask_to_segments(M)
+        elif _is_torch(M):
+            import torch
+            R = int(M.shape[1])
+            roa = M.argmax(dim=1).to(torch.int32)
+        else:
+            R = int(M.shape[1])
+            roa = np.asarray(M).argmax(1).astype(np.int32)
+        return self.forward_frames_segments(X_frames, ids_topk, q0, roa, R, frame_axis, frames_per_launch)
+
+    def forward_frames_segments(self, X_frames, ids_topk, q0, res_of_atom, R, frame_axis=0, frames_per_launch=0):
+        h = self._ensure()
+        lib = _lib.load()
+        n0 = self.config["em"]["N0"]
+        n_out = self.config["dm"]["N2"]
+        if frame_axis not in (0, 1) or len(X_frames.shape) != 3 or X_frames.shape[2] != 3:
+            raise ValueError("X_frames must be [F,N,3] (frame_axis=0) or [N,F,3] (frame_axis=1)")
+        F, N = (X_frames.shape[0], X_frames.shape[1]) if frame_axis == 0 else (X_frames.shape[1], X_frames.shape[0])
+        if _is_torch(X_frames) and X_frames.is_cuda:
+            import torch
+            dev = X_frames.device
+            if dev.index != self._gpu:
+                raise RuntimeError(f"inputs are on cuda:{dev.index} but the model is on cuda:{self._gpu} (use .to())")
+            Xc = X_frames.detach()
+            if Xc.dtype != torch.float32 or Xc.stride(2) != 1:
+                Xc = Xc.to(torch.float32).contiguous()
+            fs, as_ = (Xc.stride(0), Xc.stride(1)) if frame_axis == 0 else (Xc.stride(1), Xc.stride(0))
+            ids = ids_topk.detach()
+            if ids.dtype not in (torch.int32, torch.int64):
+                ids = ids.to(torch.int64)
+            ids = ids.to(dev).contiguous()
+            qc = q0.detach().to(device=dev, dtype=torch.float32).contiguous()
+            roa = res_of_atom if _is_torch(res_of_atom) else torch.as_tensor(np.asarray(res_of_atom))
+            roa = roa.to(device=dev, dtype=torch.int32).contiguous()
+            if ids.shape[0] != N:
+                raise ValueError(f"ids_topk has {ids.shape[0]} rows, frames have {N} atoms")
+            self._check_shapes(N, (N, 3), qc.shape, roa.shape, n0)
+            z = torch.empty((F, R, n_out), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.pesto_forward_frames(h, N, R, ids.shape[1], F, Xc.data_ptr(), fs, as_, ids.data_ptr(),
+                                                _lib.IDS_INT64 if ids.dtype == torch.int64 else _lib.IDS_INT32, qc.data_ptr(),
+                                                roa.data_ptr(), z.data_ptr(), frames_per_launch, _lib.PTR_DEVICE, stream))
+            return z
+        as_torch = _is_torch(X_frames)
+        Xn = np.asarray(X_frames.detach().numpy() if as_torch else X_frames)
+        if Xn.dtype != np.float32 or Xn.strides[2] != 4 or Xn.strides[0] % 4 or Xn.strides[1] % 4:
+            Xn = np.ascontiguousarray(Xn, dtype=np.float32)
+        fs, as_ = (Xn.strides[0] // 4, Xn.strides[1] // 4) if frame_axis == 0 else (Xn.strides[1] // 4, Xn.strides[0] // 4)
+        idn = ids_topk.detach().numpy() if _is_torch(ids_topk) else np.asarray(ids_topk)
+        if idn.dtype not in (np.int32, np.int64):
+            idn = idn.astype(np.int64)
+        idn = np.ascontiguousarray(idn)
+        qn = np.ascontiguousarray(q0.detach().numpy() if _is_torch(q0) else q0, dtype=np.float32)
+        roa = np.ascontiguousarray(res_of_atom.detach().cpu().numpy() if _is_torch(res_of_atom) else res_of_atom, dtype=np.int32)
+        if idn.shape[0] != N:
+            raise ValueError(f"ids_topk has {idn.shape[0]} rows, frames have {N} atoms")
+        self._check_shapes(N, (N, 3), qn.shape, roa.shape, n0)
+        z = np.empty((F, R, n_out), dtype=np.float32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(lib.pesto_forward_frames(h, N, R, idn.shape[1], F, p(Xn), fs, as_, p(idn),
+                                            _lib.IDS_INT64 if idn.dtype == np.int64 else _lib.IDS_INT32, p(qn), p(roa), p(z),
+                                            frames_per_launch, _lib.PTR_HOST, None))
+        if as_torch:
+            import torch
+            return torch.from_numpy(z)
+        return z
+
+    # ------------------------------------------------------------------ post-processing on the GPU (SURVEY 8f row 4)
+    def postprocess(self, z, M_or_res_of_atom=None):
+        """(p, bfactor): p = sigmoid(z) [R, N2] (apply_model.ipynb:160) and, when the residue mask M [N,R] (or res_of_atom [N]) is
+        given, bfactor [N2, N] with bfactor[c][i] = p[residue of atom i][c] - encode_bfactor's per-residue branch
+        (src/structure.py:208-218) for every output channel at once. ROCm tensors stay on the GPU (asynchronous)."""
+        h = self._ensure()
+        lib = _lib.load()
+        n_out = self.config["dm"]["N2"]
+        R = int(z.shape[0])
+        roa = None
+        if M_or_res_of_atom is not None:
+            m = M_or_res_of_atom
+            if len(m.shape) == 2:
+                if int(m.shape[1]) != R:
+                    raise ValueError(f"M has {m.shape[1]} residue columns, z has {R} rows")
+                roa = m.argmax(1)
+            else:
+                roa = m
+        if _is_torch(z) and z.is_cuda:
+            import torch
+            zc = z.detach().to(torch.float32).contiguous()
+            p = torch.empty_like(zc)
+            bf, rp, N = None, 0, 1
+            if roa is not None:
+                roa = (roa if _is_torch(roa) else torch.as_tensor(np.asarray(roa))).to(device=z.device, dtype=torch.int32).contiguous()
+                N = int(roa.shape[0])
+                bf = torch.empty((n_out, N), dtype=torch.float32, device=z.device)
+                rp = roa.data_ptr()
+            stream = torch.cuda.current_stream(z.device).cuda_stream
+            _lib.check(lib.pesto_postprocess(h, N, R, zc.data_ptr(), rp, p.data_ptr(), bf.data_ptr() if bf is not None else 0,
+                                             _lib.PTR_DEVICE, stream))
+            return p, bf
+        as_torch = _is_torch(z)
+        zn = np.ascontiguousarray(z.detach().numpy() if as_torch else z, dtype=np.float32)
+        p = np.empty_like(zn)
+        bf, N, rp = None, 1, None
+        if roa is not None:
+            roa = np.ascontiguousarray(roa.detach().cpu().numpy() if _is_torch(roa) else roa, dtype=np.int32)
+            N = int(roa.shape[0])
+            bf = np.empty((n_out, N), dtype=np.float32)
+            rp = roa.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(lib.pesto_postprocess(h, N, R, zn.ctypes.data_as(ctypes.c_void_p), rp, p.ctypes.data_as(ctypes.c_void_p),
+                                         bf.ctypes.data_as(ctypes.c_void_p) if bf is not None else None, _lib.PTR_HOST, None))
+        if as_torch:
+            import torch
+            return torch.from_numpy(p), (torch.from_numpy(bf) if bf is not None else None)
+        return p, bf
+
     # ------------------------------------------------------------------ k-NN topology + collate on the GPU (SURVEY 8f row 1)
     def knn_collate(self, X, sizes, k=64):
         """ids_topk [sum(sizes), 64] for a concatenated batch: what ``extract_topology(X_s, 64)[0]`` per structure followed by

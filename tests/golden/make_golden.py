@@ -288,6 +288,39 @@ def main():
     save("topology_synth50", X=X.numpy(), ids_topk0=extract_topology(X, 64)[0].numpy().astype(np.int32))
 
 
+def main_next():
+    """Goldens for the SURVEY 8f rows built after the forward pass: trajectory frames (md_analysis/apply_model_md.ipynb cell 6)
+    and the sigmoid / encode_bfactor post-op (apply_model.ipynb:157-166, src/structure.py:185-223)."""
+    cfg, model = load_run("i_v4_0_2021-09-07_11-20")
+    from src.structure import encode_bfactor
+    st = parse_pdb(os.path.join(REF, "examples", "issue_19_04_2023", "2CUA_A.pdb"))
+    X, ids, q, M = encode(st, False)
+    _, idsc, qc, Mc = collate([[X, ids, q, M]])          # frame-0 topology + sink offset, as the MD notebook does
+    rng = np.random.default_rng(21)
+    frames = [X.numpy()]
+    for f in range(1, 4):                                 # thermal-like displacement growing with the frame index
+        frames.append((X.numpy() + rng.normal(0.0, 0.15 * f, X.shape)).astype(np.float32))
+    Xf = np.stack(frames, 1)                              # the notebook's layout: [N, frames, 3]
+    z = np.stack([run_forward(model, pt.from_numpy(np.ascontiguousarray(Xf[:, f])), idsc, qc, Mc) for f in range(Xf.shape[1])])
+    p = pt.sigmoid(pt.from_numpy(z[0]))
+    st["het_flag"] = np.array(["A"] * X.shape[0])
+    bf = np.stack([encode_bfactor(dict(st), p[:, c].numpy())["bfactor"] for c in range(p.shape[1])])
+    save("frames_i_v4_0_2CUA", X_traj=Xf, ids_topk=idsc.numpy().astype(np.int32), q_idx=onehot_to_idx(q, False),
+         res_of_atom=res_of_atom(Mc), z=z, p0=p.numpy(), bfactor0=bf.astype(np.float32))
+    # N < 64: zero-padded ids wrap to the LAST atom of each frame and the max(D) fix-up is per frame (per call in the reference)
+    X, ids, q, M = synth_inputs(40, 5)
+    _, idsc, qc, Mc = collate([[X, ids, q, M]])
+    frames = [X.numpy()] + [(X.numpy() + rng.normal(0.0, 0.3, X.shape)).astype(np.float32) for _ in range(2)]
+    Xf = np.stack(frames, 0)                              # [frames, N, 3]
+    z = np.stack([run_forward(model, pt.from_numpy(Xf[f]), idsc, qc, Mc) for f in range(Xf.shape[0])])
+    save("frames_i_v4_0_n40", X_frames=Xf, ids_topk=idsc.numpy().astype(np.int32), q_idx=onehot_to_idx(q, False),
+         res_of_atom=res_of_atom(Mc), z=z)
+
+
 if __name__ == "__main__":
     sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
-    main()
+    if "--next" in sys.argv:      # only the 8f-row goldens (the others are unchanged)
+        main_next()
+    else:
+        main()
+        main_next()

@@ -271,3 +271,89 @@ def test_knn_feeds_forward_end_to_end():
     roa = g["res_of_atom"]
     z = m.forward_segments(g["X"], ids, onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
     assert np.abs(z - g["z"]).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- trajectory frames
+def test_frames_match_reference_md_loop_golden():
+    """forward_frames == the reference's per-frame loop with frame-0 topology (md_analysis/apply_model_md.ipynb cell 6),
+    in the notebook's own [N, frames, 3] layout (strided, read in place)."""
+    g = golden("frames_i_v4_0_2CUA")
+    m = _model("i_v4_0")
+    q = onehot(g["q_idx"], 30)
+    R = g["z"].shape[1]
+    z = m.forward_frames_segments(g["X_traj"], g["ids_topk"], q, g["res_of_atom"], R, frame_axis=1)
+    assert z.shape == g["z"].shape
+    assert np.abs(z - g["z"]).max() < 1e-4
+    # bit-identical to separate single-frame calls, whatever the launch grouping
+    singles = np.stack([m.forward_segments(np.ascontiguousarray(g["X_traj"][:, f]), g["ids_topk"], q, g["res_of_atom"], R)
+                        for f in range(z.shape[0])])
+    assert np.array_equal(z, singles)
+    for fpl in (1, 3):
+        assert np.array_equal(m.forward_frames_segments(g["X_traj"], g["ids_topk"], q, g["res_of_atom"], R, 1, fpl), singles)
+
+
+def test_frames_small_structure_per_frame_wrap_and_max():
+    """N < 64: padded ids wrap to the last atom OF THE FRAME and max(D) is per frame (per call in the reference)."""
+    g = golden("frames_i_v4_0_n40")
+    m = _model("i_v4_0")
+    q = onehot(g["q_idx"], 30)
+    z = m.forward_frames_segments(g["X_frames"], g["ids_topk"].astype(np.int64), q, g["res_of_atom"], g["z"].shape[1])
+    assert np.abs(z - g["z"]).max() < 1e-4
+
+
+def test_frames_device_tensors_strided_view():
+    import torch
+    g = golden("frames_i_v4_0_2CUA")
+    m = _model("i_v4_0").to("cuda")
+    R = g["z"].shape[1]
+    M = np.zeros((g["X_traj"].shape[0], R), np.float32)
+    M[np.arange(M.shape[0]), g["res_of_atom"]] = 1.0
+    Xt = torch.from_numpy(g["X_traj"]).cuda()                      # [N, F, 3] as in the notebook
+    z = m.forward_frames(Xt, torch.from_numpy(g["ids_topk"].astype(np.int64)).cuda(), torch.from_numpy(onehot(g["q_idx"], 30)).cuda(),
+                         torch.from_numpy(M).cuda(), frame_axis=1)
+    assert z.is_cuda and tuple(z.shape) == g["z"].shape
+    assert np.abs(z.cpu().numpy() - g["z"]).max() < 1e-4
+    z2 = m.forward_frames(Xt.transpose(0, 1)[1:3], torch.from_numpy(g["ids_topk"]).cuda(), torch.from_numpy(onehot(g["q_idx"], 30)).cuda(),
+                          torch.from_numpy(M).cuda(), frame_axis=0)   # a non-contiguous [F', N, 3] view
+    assert torch.equal(z2, z[1:3])
+
+
+def test_frames_bad_arguments():
+    from pesto_amd._lib import PestoError
+    g = golden("frames_i_v4_0_n40")
+    m = _model("i_v4_0")
+    q = onehot(g["q_idx"], 30)
+    with pytest.raises(ValueError):
+        m.forward_frames_segments(g["X_frames"][:, :30], g["ids_topk"], q, g["res_of_atom"], g["z"].shape[1])
+    bad = g["ids_topk"].copy()
+    bad[3, 2] = 41                                                  # > N: would alias an atom of the NEXT frame in the batch
+    with pytest.raises(PestoError):
+        m.forward_frames_segments(g["X_frames"], bad, q, g["res_of_atom"], g["z"].shape[1])
+    z = m.forward_frames_segments(g["X_frames"], g["ids_topk"], q, g["res_of_atom"], g["z"].shape[1])   # handle still usable
+    assert np.abs(z - g["z"]).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- post-processing (SURVEY 8f row 4)
+def test_postprocess_matches_reference_sigmoid_and_encode_bfactor():
+    import torch
+    g = golden("frames_i_v4_0_2CUA")
+    m = _model("i_v4_0")
+    p, bf = m.postprocess(g["z"][0], g["res_of_atom"])
+    assert np.abs(p - g["p0"]).max() < 1e-6          # same z in: only the exp implementation differs
+    assert bf.shape == g["bfactor0"].shape and np.abs(bf - g["bfactor0"]).max() < 1e-6
+    assert np.array_equal(bf, p[g["res_of_atom"]].T)
+    # end to end on device tensors: forward -> sigmoid -> atoms, nothing leaves the GPU in between
+    m = m.to("cuda")
+    q = onehot(g["q_idx"], 30)
+    R = g["z"].shape[1]
+    M = np.zeros((q.shape[0], R), np.float32)
+    M[np.arange(M.shape[0]), g["res_of_atom"]] = 1.0
+    Md = torch.from_numpy(M).cuda()
+    z = m(torch.from_numpy(np.ascontiguousarray(g["X_traj"][:, 0])).cuda(), torch.from_numpy(g["ids_topk"].astype(np.int64)).cuda(),
+          torch.from_numpy(q).cuda(), Md)
+    p, bf = m.postprocess(z, Md)
+    assert p.is_cuda and bf.is_cuda
+    assert np.abs(p.cpu().numpy() - g["p0"]).max() < 1e-5     # SURVEY 8c: 1e-5 on sigmoid(z)
+    assert np.abs(bf.cpu().numpy() - g["bfactor0"]).max() < 1e-5
+    p_only, none = m.postprocess(z)
+    assert none is None and torch.equal(p_only, p)

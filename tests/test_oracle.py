@@ -106,3 +106,19 @@ def test_batch_equals_singles():
     # one cross-structure coupling the reference has. It is pinned by the golden above instead.
     assert np.abs(zb[:r0] - z0).max() < 2e-5
     assert np.abs(zb - g["z"]).max() < 1e-4
+
+
+def test_oracle_frames_fixed_topology_goldens():
+    """MD use (md_analysis/apply_model_md.ipynb cell 6): frame-0 topology, per-frame coordinates, one reference call per frame."""
+    o = oracle.OracleModel(CONFIGS["i_v4_0"], weights("i_v4_0"))
+    g = golden("frames_i_v4_0_2CUA")
+    q = onehot(g["q_idx"], 30)
+    R = g["z"].shape[1]
+    for f in range(g["z"].shape[0]):
+        z = o.forward_segments(np.ascontiguousarray(g["X_traj"][:, f]), g["ids_topk"], q, g["res_of_atom"], R)
+        assert np.abs(z - g["z"][f]).max() < 1e-4
+    g = golden("frames_i_v4_0_n40")
+    q = onehot(g["q_idx"], 30)
+    for f in range(g["z"].shape[0]):
+        z = o.forward_segments(g["X_frames"][f], g["ids_topk"], q, g["res_of_atom"], g["z"].shape[1])
+        assert np.abs(z - g["z"][f]).max() < 1e-4
