@@ -13,6 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["pesto_schema.cpp", "pesto_kernels.hip", "pesto_layer_mfma.hip", "pesto_api.hip"]
 HEADERS = ["pesto_schema.h", "pesto_kernels.h", os.path.join("..", "..", "include", "pesto_hip.h")]
 OUT = os.path.join(HERE, "libpesto_hip.so")
+# host-only structure I/O library (include/pesto_io.h): plain C++, no HIP runtime, safe in forked data-loader workers
+IO_SOURCE = "pesto_io.cpp"
+IO_OUT = os.path.join(HERE, "libpesto_io.so")
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent f32 adds/muls of the edge kernel into v_pk_*_f32 and pays for it with
 # ~5x more v_mov_b32 shuffles than it saves (665 -> 138 v_mov, mul+add re-fused into v_fmac) - measured +% in DESIGN.md
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
@@ -62,7 +65,20 @@ def build(force=False, verbose=True):
     objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in srcs]
     if force or jobs or _stale(OUT, objs):
         run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    build_io(force, verbose)
     return OUT
+
+
+def build_io(force=False, verbose=True):
+    src = os.path.join(HERE, IO_SOURCE)
+    hdr = os.path.join(HERE, "..", "..", "include", "pesto_io.h")
+    if force or _stale(IO_OUT, [src, hdr]):
+        cxx = shutil.which("g++") or hipcc()
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", IO_OUT, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return IO_OUT
 
 
 if __name__ == "__main__":

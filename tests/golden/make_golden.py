@@ -317,10 +317,126 @@ def main_next():
          res_of_atom=res_of_atom(Mc), z=z)
 
 
+def _pdb_line(rec, serial, name, alt, resname, chain, resnum, icode, xyz, element, occ=1.0, b=20.0):
+    name4 = name if len(name) == 4 else " " + name.ljust(3)
+    return "%-6s%5d %4s%1s%3s %1s%4d%1s   %8.3f%8.3f%8.3f%6.2f%6.2f          %2s  " % (
+        rec, serial, name4, alt, resname, chain, resnum, icode, xyz[0], xyz[1], xyz[2], occ, b, element.upper().rjust(2))
+
+
+def synthetic_pdb_text():
+    """A small two-model file written for this test suite: insertion code, alternate locations (also across models), water,
+    heavy water, H and D atoms, a CA-only chain, ions and ligands, duplicated ligands between the models."""
+    rng = np.random.default_rng(5)
+    lines, serial = ["HEADER    SYNTHETIC TEST STRUCTURE", "REMARK   1 two models"], 0
+    for mid in (1, 2):
+        lines.append("MODEL     %4d" % mid)
+        shift = np.array([0.0, 0.0, 12.0 * (mid - 1)])
+
+        def add(rec, name, alt, resname, chain, num, icode, xyz, el):
+            nonlocal serial
+            serial += 1
+            lines.append(_pdb_line(rec, serial, name, alt, resname, chain, num, icode, np.asarray(xyz) + shift, el))
+        base = np.array([10.0, 5.0, 3.0])
+        for k, (rn, num, ic, names) in enumerate([("ALA", 1, " ", ["N", "CA", "C", "O", "CB", "H", "HA"]),
+                                                   ("GLY", 1, "A", ["N", "CA", "C", "O", "D"]),
+                                                   ("SER", 2, " ", ["N", "CA", "C", "O", "CB", "OG"]),
+                                                   ("MSE", 3, " ", ["N", "CA", "C", "O", "SE"])]):
+            for j, nm in enumerate(names):
+                xyz = base + np.array([3.8 * k, 1.3 * j, 0.4 * j]) + rng.normal(0, 0.2, 3)
+                el = {"SE": "SE", "H": "H", "HA": "H", "D": "D"}.get(nm, nm[0])
+                if rn == "SER" and nm in ("CB", "OG"):      # two alternate locations; the reference keeps the first seen key
+                    add("ATOM", nm, "A", rn, "A", num, ic, xyz, el)
+                    add("ATOM", nm, "B", rn, "A", num, ic, xyz + 0.7, el)
+                elif rn == "MSE":
+                    add("HETATM", nm, " ", rn, "A", num, ic, xyz, el)
+                else:
+                    add("ATOM", nm, " ", rn, "A", num, ic, xyz, el)
+        lines.append("TER")
+        for k in range(3):                                   # CA-only chain: one atom per residue -> filtered out
+            add("ATOM", "CA", " ", "LYS", "B", 10 + k, " ", base + [3.8 * k, -8.0, 0.0], "C")
+        lines.append("TER")
+        lig = np.array([25.0, 9.0, 4.0]) - shift              # ligands at (almost) the same place in both models -> duplicates
+        add("HETATM", "ZN", " ", " ZN", "A", 201, " ", lig, "ZN")
+        for j, (nm, el) in enumerate([("S", "S"), ("O1", "O"), ("O2", "O"), ("O3", "O"), ("O4", "O")]):
+            add("HETATM", nm, " ", "SO4", "A", 202, " ", lig + [4.0 + 1.2 * j, 0.3 * j, 0.05 * (mid - 1)], el)
+        add("HETATM", "FE", " ", "HEM", "C", 301, " ", base + [0.0, 9.0, 12.0 * (mid - 1) * 0 + 3.0 * mid], "FE")   # not duplicates
+        add("HETATM", "O", " ", "HOH", "A", 401, " ", base + [1.0, 1.0, 8.0], "O")
+        add("HETATM", "O", " ", "DOD", "A", 402, " ", base + [2.0, 1.0, 8.0], "O")
+        lines.append("ENDMDL")
+    lines.append("END")
+    return "\n".join(lines) + "\n"
+
+
+def main_io():
+    """Goldens for the native structure I/O: the reference's own preprocessing / encoding / writing
+    functions applied to the dict the native reader produces (the reference's reader needs gemmi, absent here - the reader is
+    pinned separately by the reference's examples/*.pdb -> *_i0.pdb pairs copied to tests/golden/pdb/)."""
+    import gzip
+    import shutil
+    import tempfile
+    import_reference("i_v4_0_2021-09-07_11-20")     # installs the gemmi stub
+    # the repository's own src/ (what apply_model.ipynb imports), not the older snapshot stored inside the run directory
+    sys.path = [REF] + [p for p in sys.path if "/model/save/" not in p and p != REF]
+    for m in [m for m in sys.modules if m == "src" or m.startswith("src.")]:
+        sys.modules.pop(m)
+    from src.structure import (clean_structure, tag_hetatm_chains, split_by_chain, filter_non_atomic_subunits,
+                               remove_duplicate_tagged_subunits, concatenate_chains, encode_bfactor)
+    from src.data_encoding import encode_structure, encode_features
+    from src.structure_io import save_pdb
+    from pesto_amd.structure_io import Structure
+    os.makedirs(os.path.join(OUT, "pdb"), exist_ok=True)
+    ex = os.path.join(REF, "examples")
+    cases = {"synthetic": synthetic_pdb_text()}
+    for rel in ("lipids/7KHT_lipid", "double/1thf_D", "lipids/6I9F", "endonuclease/1ZNS_ion"):
+        name = os.path.basename(rel)
+        for suffix in (".pdb", "_i0.pdb"):               # reference DATA files: an input and the output the reference saved for it
+            src = os.path.join(ex, rel + suffix)
+            if os.path.exists(src):
+                with open(src, "rb") as fi, gzip.GzipFile(os.path.join(OUT, "pdb", name + suffix + ".gz"), "wb", mtime=0) as fo:
+                    shutil.copyfileobj(fi, fo)
+        cases[name] = open(os.path.join(ex, rel + ".pdb")).read()
+    rng = np.random.default_rng(9)
+    for name, text in cases.items():
+        st = Structure.parse_pdb(text).to_dict()
+        st["resid"] = st["resid"].astype(np.int32)
+        out = {"pdb_text": np.frombuffer(text.encode(), dtype=np.uint8)}
+        s = clean_structure({k: v.copy() for k, v in st.items()})
+        out.update(clean_resid=s["resid"], clean_chain=s["chain_name"].astype("S"), clean_name=s["name"].astype("S"))
+        s = tag_hetatm_chains(s)
+        out["tag_chain"] = s["chain_name"].astype("S")
+        sub = split_by_chain(s)
+        out["split_keys"] = np.array(list(sub)).astype("S")
+        sub = filter_non_atomic_subunits(sub)
+        out["filter_keys"] = np.array(list(sub)).astype("S")
+        sub = remove_duplicate_tagged_subunits(sub)
+        out["dedup_keys"] = np.array(list(sub)).astype("S")
+        s = concatenate_chains(sub)
+        for k in ("xyz", "resid"):
+            out["final_" + k] = s[k]
+        for k in ("name", "element", "resname", "het_flag", "chain_name"):
+            out["final_" + k] = s[k].astype("S")
+        X, M = encode_structure(s)
+        qe, qr, qn = encode_features(s)
+        out["M_col"] = M.numpy().argmax(1).astype(np.int32)
+        out["n_res"] = np.int64(M.shape[1])
+        out["q_idx"] = np.stack([qe.numpy().argmax(1), qr.numpy().argmax(1), qn.numpy().argmax(1)], 1).astype(np.int16)
+        p = rng.uniform(0, 1, M.shape[1]).astype(np.float32)       # a per-residue prediction
+        s = encode_bfactor(s, p)
+        with tempfile.TemporaryDirectory() as tmp:
+            save_pdb(split_by_chain(s), os.path.join(tmp, "o.pdb"))
+            out["saved_text"] = np.frombuffer(open(os.path.join(tmp, "o.pdb"), "rb").read(), dtype=np.uint8)
+        out["p_res"] = p
+        out["bfactor"] = s["bfactor"].astype(np.float32)
+        save("io_" + name, **out)
+
+
 if __name__ == "__main__":
     sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
     if "--next" in sys.argv:      # only the 8f-row goldens (the others are unchanged)
         main_next()
+    elif "--io" in sys.argv:
+        main_io()
     else:
         main()
         main_next()
+        main_io()

@@ -357,3 +357,34 @@ def test_postprocess_matches_reference_sigmoid_and_encode_bfactor():
     assert np.abs(bf.cpu().numpy() - g["bfactor0"]).max() < 1e-5
     p_only, none = m.postprocess(z)
     assert none is None and torch.equal(p_only, p)
+
+
+# ---------------------------------------------------------------------------------------------- apply_model.ipynb cell 6, natively
+def test_apply_model_chain_pdb_to_bfactor_pdb(tmp_path):
+    """PDB text -> native read/clean/encode -> GPU k-NN -> forward -> GPU sigmoid/expansion -> native b-factor PDB, against the
+    same chain assembled from the checked pieces (host topology contract, CPU oracle, numpy sigmoid)."""
+    import gzip
+    import os
+    from conftest import GOLDEN
+    from pesto_amd.structure_io import Structure
+    from pesto_amd.topology import extract_topology
+    text = gzip.open(os.path.join(GOLDEN, "pdb", "7KHT_lipid.pdb.gz"), "rt").read()
+    s = Structure.parse_pdb(text).preprocess()
+    X, q, roa, R = s.encode(30)
+    m = _model("i_v4_0")
+    ids = m.knn_collate(X, [len(s)])
+    ids_host = extract_topology(X, 64) + 1
+    _check_same_neighbours(ids, ids_host, X)
+    z = m.forward_segments(X, ids, q, roa, R)
+    zo = _oracle("i_v4_0").forward_segments(X, ids.astype(np.int32), q, roa, R)
+    assert np.abs(z - zo).max() < 1e-4
+    p, bf = m.postprocess(z, roa)
+    assert np.abs(p - 1.0 / (1.0 + np.exp(-zo.astype(np.float64)))).max() < 1e-5
+    out = tmp_path / "7KHT_lipid_i0.pdb"
+    s.save_pdb(str(out), bf[0])
+    lines = out.read_text().split("\n")
+    want = gzip.open(os.path.join(GOLDEN, "pdb", "7KHT_lipid_i0.pdb.gz"), "rt").read().split("\n")
+    assert len(lines) == len(want)
+    atoms = [l for l in lines if l.startswith(("ATOM", "HETATM"))]
+    assert [l[:54] for l in atoms] == [l[:54] for l in want if l.startswith(("ATOM", "HETATM"))]
+    assert [float(l[54:60]) for l in atoms] == [float("%.2f" % v) for v in bf[0]]

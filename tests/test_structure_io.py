@@ -1,0 +1,133 @@
+"""Native structure I/O (libpesto_io.so) against the reference. No GPU needed.
+ * the reader + the whole preprocessing chain + the writer: the reference's own examples/*.pdb -> *_i0.pdb pairs (data files
+   copied to tests/golden/pdb/): every column of every line except the b-factor value (the i_v4_1 checkpoint that produced it
+   is not in the reference tree);
+ * each preprocessing stage, the encoders and the b-factor writer: outputs of the reference's Python functions captured by
+   tests/golden/make_golden.py --io."""
+import gzip
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden
+from pesto_amd import structure_io as sio
+from pesto_amd.structure_io import Structure
+
+PAIRS = ["7KHT_lipid", "1thf_D", "6I9F"]
+CASES = ["synthetic", "7KHT_lipid", "1thf_D", "6I9F", "1ZNS_ion"]
+
+
+def _gz(name):
+    return gzip.open(os.path.join(GOLDEN, "pdb", name + ".gz"), "rt").read()
+
+
+def _text(g, key):
+    return g[key].tobytes().decode()
+
+
+def _s(arr):
+    return np.char.decode(arr, "ascii") if arr.dtype.kind == "S" else arr
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "pesto_io.h")).read()
+    declared = set(re.findall(r"\b(pesto_io_[a-z_]+)\s*\(", hdr))
+    assert declared == set(sio.ABI_SYMBOLS)
+    lib = sio.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+@pytest.mark.parametrize("name", PAIRS)
+def test_read_preprocess_write_matches_reference_example_outputs(name, tmp_path):
+    """apply_model.ipynb cell 6 end to end (minus the model): read_pdb -> clean -> tag -> split -> filter -> dedup ->
+    concatenate -> save_pdb equals the file the reference saved, in every column but the b-factor value."""
+    src = tmp_path / (name + ".pdb")
+    src.write_text(_gz(name + ".pdb"))
+    out = tmp_path / "out.pdb"
+    Structure.read_pdb(str(src)).preprocess().save_pdb(str(out))
+    strip = lambda l: l[:54] + l[66:] if l.startswith(("ATOM", "HETATM")) else l
+    got = [strip(l) for l in out.read_text().split("\n")]
+    want = [strip(l) for l in _gz(name + "_i0.pdb").split("\n")]
+    assert got == want
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_preprocessing_stages_match_reference_functions(name):
+    g = golden("io_" + name)
+    text = _text(g, "pdb_text")
+    s = Structure.parse_pdb(text).preprocess(sio.CLEAN)                       # clean_structure
+    d = s.to_dict()
+    assert "icode" not in d
+    assert np.array_equal(d["resid"], g["clean_resid"])
+    assert np.array_equal(d["chain_name"], _s(g["clean_chain"])) and np.array_equal(d["name"], _s(g["clean_name"]))
+    s.preprocess(sio.TAG_HETATM)                                               # tag_hetatm_chains
+    assert np.array_equal(s.to_dict()["chain_name"], _s(g["tag_chain"]))
+    assert list(s.subunits()) == list(_s(g["split_keys"]))                     # split_by_chain (sorted keys)
+    f = Structure.parse_pdb(text).preprocess(sio.CLEAN | sio.TAG_HETATM | sio.FILTER_NON_ATOMIC)
+    assert list(f.subunits()) == list(_s(g["filter_keys"]))                    # filter_non_atomic_subunits
+    s = Structure.parse_pdb(text).preprocess()                                 # ... remove_duplicate_tagged_subunits, concatenate_chains
+    assert list(s.subunits()) == list(_s(g["dedup_keys"]))
+    d = s.to_dict()
+    assert np.array_equal(d["xyz"], g["final_xyz"]) and np.array_equal(d["resid"], g["final_resid"])
+    for k in ("name", "element", "resname", "het_flag", "chain_name"):
+        assert np.array_equal(d[k], _s(g["final_" + k])), k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_encode_and_bfactor_writer_match_reference(name, tmp_path):
+    g = golden("io_" + name)
+    s = Structure.parse_pdb(_text(g, "pdb_text")).preprocess()
+    X, q, roa, R = s.encode(123)                                               # encode_structure + encode_features
+    assert R == int(g["n_res"]) and np.array_equal(roa, g["M_col"]) and np.array_equal(X, g["final_xyz"])
+    assert np.all(q.sum(1) == 3)
+    idx = np.stack([q[:, :30].argmax(1), q[:, 30:59].argmax(1), q[:, 59:].argmax(1)], 1)
+    assert np.array_equal(idx, g["q_idx"])
+    q30 = s.encode(30)[1]
+    assert np.array_equal(q30, q[:, :30])
+    M = s.mask()
+    assert M.shape == (len(s), R) and np.array_equal(M.argmax(1), roa)
+    # encode_bfactor (per-residue p) + save_pdb: byte-identical file
+    assert s.format_pdb(g["p_res"]) == _text(g, "saved_text")
+    s.save_pdb(str(tmp_path / "o.pdb"), g["bfactor"])                           # per-atom values
+    assert (tmp_path / "o.pdb").read_text() == _text(g, "saved_text")
+    with pytest.raises(sio.PestoIOError):
+        s.format_pdb(np.zeros(R + 1, np.float32))
+
+
+def test_reference_named_entry_points(tmp_path):
+    """read_pdb / StructuresDataset / save_pdb keep the reference's signatures and dict layout."""
+    g = golden("io_synthetic")
+    path = tmp_path / "syn.pdb"
+    path.write_text(_text(g, "pdb_text"))
+    st = sio.read_pdb(str(path))
+    assert set(st) == {"xyz", "name", "element", "resname", "resid", "het_flag", "chain_name", "icode"}
+    assert st["xyz"].dtype == np.float32 and st["resid"].dtype == np.int32
+    assert set(np.unique(st["chain_name"])) == {"A:0", "B:0", "C:0", "A:1", "B:1", "C:1"}
+    assert "A" in set(st["icode"]) and "H" in set(st["het_flag"]) and {"Se", "Zn", "Fe", "H", "D"} <= set(st["element"])
+    # alternate locations: the first seen (chain, number, name) key wins - also across models, as in the reference's loop
+    ser = (st["resname"] == "SER") & (st["name"] == "OG")
+    assert ser.sum() == 1
+    ds = sio.StructuresDataset([str(path), str(tmp_path / "missing.pdb")])
+    subunits, p = ds[0]
+    assert p == str(path) and list(subunits) == list(_s(g["dedup_keys"]))
+    assert ds[1] == (None, str(tmp_path / "missing.pdb"))
+    for su in subunits.values():
+        su["bfactor"] = np.full(su["xyz"].shape[0], 0.5, np.float32)
+    sio.save_pdb(subunits, str(tmp_path / "o.pdb"))
+    lines = (tmp_path / "o.pdb").read_text().split("\n")
+    assert lines[-1] == "END" and lines[0][60:66] == "  0.50" and sum(l == "TER" for l in lines) == len(subunits)
+    native, _ = sio.StructuresDataset([str(path)], as_structure=True)[0]
+    assert native.format_pdb(np.full(len(native), 0.5, np.float32)) == "\n".join(lines)
+
+
+def test_parse_errors_are_reported():
+    with pytest.raises(sio.PestoIOError):
+        Structure.parse_pdb("ATOM      1  N   ALA A   1      30.837\n")           # too short to hold coordinates
+    with pytest.raises(sio.PestoIOError):
+        Structure.parse_pdb("REMARK nothing here\nEND\n").preprocess()            # no atoms
+    water = "HETATM    1  O   HOH A   1       1.000   2.000   3.000  1.00  0.00           O  \n"
+    with pytest.raises(sio.PestoIOError):
+        Structure.parse_pdb(water).preprocess()
