@@ -271,6 +271,10 @@ __device__ __forceinline__ void node_fill(float* lds, const float* __restrict__ 
     __syncthreads();
 }
 
+// HY (hybrid edge kernel): the neighbour record shrinks to A_j[128] in natural feature order (REC_A floats per atom); the
+// C_j[c] = W[:,161:193] p_j[c] pieces are no longer materialised - the edge kernel applies that block per edge on the matrix
+// cores from the gathered p_j (4x less gather traffic than the 2 KB record, which was the edge kernel's bottleneck).
+template <bool HY>
 __global__ __launch_bounds__(256, 2) void k_node16(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
                                                 int N1, float* __restrict__ q_state, float* __restrict__ p_state,
                                                 const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen) {
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void k_node16(const float* __restrict__ W, 
     for (int c = 0; c < 3; ++c) split8(p[c][0], p[c][1], ph[c], pl[c]);
 
     float* cen = rec_cen + (size_t)i * REC_CEN;
-    float* nb = rec_nb + (size_t)i * REC_NB;
+    float* nb = rec_nb + (size_t)i * (HY ? REC_A : REC_NB);
 #pragma unroll 1
     for (int ob = 0; ob < 16; ob += 4) {
         f32x4 a[4];
@@ -387,16 +391,17 @@ __global__ __launch_bounds__(256, 2) void k_node16(const float* __restrict__ W, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);
+                else if (HY) st4(nb + (ob + j - 8) * 16 + 4 * g, a[j]);           // A_j[16 fb + 4g + r]
                 else st4(nb + ((ob + j - 8) * 4 + g) * 16, a[j]);
             }
         }
     }
-    node_fill(wl_, W + wp_.h_gc, 8192);                // [G|C] fragments (32 KB) ...
+    node_fill(wl_, W + wp_.h_gc, HY ? 4096 : 8192);    // [G|C] fragments (32 KB; the G half only on the hybrid path) ...
     for (int k = threadIdx.x; k < 3584 / 4; k += 256)  // ... followed by the nqm tables [n0 | n1 | n2] (14 KB)
         reinterpret_cast<f32x4*>(wl_ + 8192)[k] = reinterpret_cast<const f32x4*>(W + wp_.h_n0)[k];
     __syncthreads();
 #pragma unroll 1
-    for (int ob = 0; ob < 16; ob += 2) {
+    for (int ob = 0; ob < (HY ? 8 : 16); ob += 2) {
         f32x4 a[2][3];
         f16x8 wh[2], wl[2];
 #pragma unroll
@@ -478,9 +483,9 @@ struct EdgeWaveScratch {
     float zbuf[2][256];  // Zq | Zp staging per centre (two centres per tile when NN == 8)
     float z3buf[2][2][96];  // [centre sel][h][c*32+s]: sum_e w3[h][e] p_j(e), staged for the final combine
 };
-template <int WPB>
+template <int WPB, bool HY>
 struct EdgeSmem {
-    float w[EDGE_LDS_FLOATS];
+    float w[HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS];
     EdgeWaveScratch ws[WPB];
 };
 
@@ -493,7 +498,11 @@ __device__ __forceinline__ L1Ops l1_fetch(int fb, int lane, int g, const float* 
                                           const float* __restrict__ recj) {
     L1Ops o;
     const float* rp = recj + (fb * 4 + g) * 16;
+#ifdef PESTO_ABL_L1QUARTER   // ablation: a quarter of the neighbour-record gather traffic, same arithmetic (results wrong)
+    o.a4 = ld4(rp); o.c0 = o.a4; o.c1 = o.a4; o.c2 = o.a4;
+#else
     o.a4 = ld4(rp); o.c0 = ld4(rp + 4); o.c1 = ld4(rp + 8); o.c2 = ld4(rp + 12);
+#endif
     o.cenA = cenA[fb * 64 + lane];
     o.cenB = NN == 8 ? cenB[fb * 64 + lane] : 0.0f;
     return o;
@@ -515,7 +524,7 @@ __device__ __forceinline__ f32x4 l1_compute(const L1Ops& o, int fb, int g, float
 // per-tile addressing: centre record(s), neighbour record of this lane's edge, geometry
 struct TileCtx { const float *cenA, *cenB, *recj; float rx, ry, rz, d, bgA, bgB; };
 
-template <int NN>
+template <int NN, bool HY = false>
 __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1, const EdgeWaveScratch& ws,
                                             const float* __restrict__ rec_nb, const float* __restrict__ rec_cen) {
     TileCtx c;
@@ -530,9 +539,59 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
 #ifdef PESTO_ABL_NOGATHER
     c.recj = rec_nb + (size_t)(row & 7) * REC_NB;      // ablation: every edge reads one of 8 hot records
 #else
-    c.recj = rec_nb + (size_t)ws.nb[row] * REC_NB;
+    c.recj = rec_nb + (size_t)ws.nb[row] * (HY ? REC_A : REC_NB);
 #endif
     return c;
+}
+
+// ---- hybrid first layer: neighbour terms = A_j (gathered, 512 B) + W[:,161:193] (p_j . r) on the matrix cores
+// B operand of the W1P MFMAs for one tile: lane (edge e, kg = g) holds p_j(e) . r_hat for s = 8g .. 8g+7, as f16 hi/lo
+struct TileFeat { f16x8 h, l; };
+__device__ __forceinline__ TileFeat tile_feat(const float* __restrict__ p_state, int nbj, int g, float rx, float ry, float rz) {
+    const float* pj = p_state + (size_t)nbj * 96 + 8 * g;
+    const f32x4 x0 = ld4(pj), x1 = ld4(pj + 4), y0 = ld4(pj + 32), y1 = ld4(pj + 36), z0 = ld4(pj + 64), z1 = ld4(pj + 68);
+    f32x4 a, b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        a[r] = x0[r] * rx + y0[r] * ry + z0[r] * rz;      // model_operations.py:115
+        b[r] = x1[r] * rx + y1[r] * ry + z1[r] * rz;
+    }
+    TileFeat f;
+    split8(a, b, f.h, f.l);
+    return f;
+}
+// h1 of the four feature blocks fb0 .. fb0+3 of one tile
+template <int NN>
+__device__ __forceinline__ void l1_tile_hy(int fb0, int lane, int g, const TileCtx& tc, const TileFeat& tf, const float* __restrict__ w1p,
+                                           const float* __restrict__ wd, f32x4* h1) {
+    f32x4 acc[4], a4[4];
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        a4[fb] = ld4(tc.recj + (fb0 + fb) * 16 + 4 * g);
+        acc[fb] = MFMA(tc.cenA[(fb0 + fb) * 64 + lane], tc.bgA, (f32x4{0, 0, 0, 0}));      // sum_c G_i[c] r_c + U_i
+        if (NN == 8) acc[fb] = MFMA(tc.cenB[(fb0 + fb) * 64 + lane], tc.bgB, acc[fb]);
+    }
+#pragma unroll
+    for (int m0 = 0; m0 < 4; m0 += 2) {
+        f16x8 wh[2], wl[2];
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml) {
+            const float* fr = w1p + (size_t)((fb0 + m0 + ml) * 2) * 256 + lane * 4;
+            wh[ml] = ld8h(fr); wl[ml] = ld8h(fr + 256);
+        }
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wh[ml], tf.h, acc[m0 + ml]);
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wh[ml], tf.l, acc[m0 + ml]);
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wl[ml], tf.h, acc[m0 + ml]);
+    }
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        const f32x4 w4 = ld4(wd + 16 * (fb0 + fb) + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[fb][r] = elu_f(acc[fb][r] + a4[fb][r] + tc.d * w4[r]);
+    }
 }
 
 // WPB = waves per workgroup: 4 (two workgroups per CU, 2 waves/SIMD, needs the explicit cross-tile prefetch PF)
@@ -551,20 +610,21 @@ __device__ __forceinline__ void l1_tile_lean(int fb0, int lane, int g, const Til
     }
 }
 
-template <int NN, int WPB, bool PF, bool F16>
+template <int NN, int WPB, bool PF, bool F16, bool HY = false>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
                                                  const float* __restrict__ p_state, float* __restrict__ Z) {
     constexpr int A = 64 / NN;                 // centres per wave work item (64 edge rows)
     constexpr int TPC = NN >= 16 ? NN / 16 : 1;   // tiles per centre
-    __shared__ EdgeSmem<WPB> sm;
+    static_assert(!HY || (F16 && !PF), "the hybrid first layer exists on the lean f16-split path only");
+    __shared__ EdgeSmem<WPB, HY> sm;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = lane & 15, g = lane >> 4;
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
         const f32x4* src = reinterpret_cast<const f32x4*>(W + (F16 ? lw.e_lds16 : lw.e_lds));
         f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
-        for (int k = threadIdx.x; k < EDGE_LDS_FLOATS / 4; k += WPB * 64) dst[k] = src[k];
+        for (int k = threadIdx.x; k < (HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS) / 4; k += WPB * 64) dst[k] = src[k];
     }
     __syncthreads();
     EdgeWaveScratch& ws = sm.ws[wave];
@@ -699,9 +759,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             } else {
 #pragma unroll 1
                 for (int t = 0; t < 4; ++t) {   // register-lean: rolled loop, operands fetched block by block
-                    const TileCtx tcc = tile_ctx<NN>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
+                    const TileCtx tcc = tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
                     f32x4 h1[4];
-                    l1_tile_lean<NN>(0, lane, g, tcc, sm.w + EL_WD, h1);
+                    if (HY) {
+                        const TileFeat tf = tile_feat(p_state, ws.nb[16 * t + e], g, tcc.rx, tcc.ry, tcc.rz);
+                        l1_tile_hy<NN>(0, lane, g, tcc, tf, sm.w + EL_W1P, sm.w + EL_WD, h1);
+                    } else {
+                        l1_tile_lean<NN>(0, lane, g, tcc, sm.w + EL_WD, h1);
+                    }
                     keys_of_tile(t, h1);
                 }
             }
@@ -766,7 +831,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
             for (int k = 0; k < 2; ++k) { zq[h][k] = 0.f; zp1[h][0][k] = zp1[h][1][k] = zp1[h][2][k] = 0.f; }
 
-        TileCtx tcn = tile_ctx<NN>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
+        TileCtx tcn = tile_ctx<NN, HY>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
         L1Ops pre[4];
         if (PF) {
 #pragma unroll
@@ -774,7 +839,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         }
         float pi_pre[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // centre's own p_i (second block of Vp, :133), fetched a tile phase early
         for (int t = 0; t < 4; ++t) {
-            const TileCtx tc = PF ? tcn : tile_ctx<NN>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
+            const TileCtx tc = PF ? tcn : tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
             if (t % TPC == 0) {
 #pragma unroll
                 for (int sel = 0; sel < (NN == 8 ? 2 : 1); ++sel) {
@@ -801,6 +866,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                 for (int fbl = 0; fbl < 4; ++fbl)
                     h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
+            } else if (HY) {
+                const TileFeat tf = tile_feat(p_state, ws.nb[16 * t + e], g, tc.rx, tc.ry, tc.rz);
+                l1_tile_hy<NN>(4, lane, g, tc, tf, sm.w + EL_W1P, sm.w + EL_WD, h1);
             } else {
                 l1_tile_lean<NN>(4, lane, g, tc, sm.w + EL_WD, h1);
             }
@@ -1025,11 +1093,12 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
                  const float* Z, float* rec_nb, float* rec_cen, int variant) {
     const int tiles = (N1 + 15) / 16, chunk = (tiles + 7) / 8;
     const LayerW dummy{};
-    hipLaunchKernelGGL(variant == 1 ? k_node : k_node16, dim3((chunk + 3) / 4 * 8), dim3(256), 0, st, W, finish ? *finish : dummy, prep ? *prep : dummy,
+    auto kern = variant == 1 ? k_node : variant == 0 ? k_node16<true> : k_node16<false>;
+    hipLaunchKernelGGL(kern, dim3((chunk + 3) / 4 * 8), dim3(256), 0, st, W, finish ? *finish : dummy, prep ? *prep : dummy,
                        finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
 }
 
-template <int WPB, bool PF, bool F16>
+template <int WPB, bool PF, bool F16, bool HY = false>
 static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                           const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks) {
     const int A = 64 / lw.nn;
@@ -1039,15 +1108,17 @@ static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int 
     if (blocks < 8) blocks = 8;
     const dim3 grid(blocks), block(WPB * 64);
     switch (lw.nn) {
-        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
-        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
-        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
-        default: hipLaunchKernelGGL((k_edge<64, WPB, PF, F16>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
+        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF, F16, HY>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
+        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF, F16, HY>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
+        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF, F16, HY>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
+        default: hipLaunchKernelGGL((k_edge<64, WPB, PF, F16, HY>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
     }
 }
 
-// variant 0 (default): 12 waves per workgroup (3 per SIMD, one workgroup per CU), register-lean first layer, f16-split MFMA
-// variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch)
+// variant 0 (default): hybrid first layer (A_j record + per-edge p_j.r block on MFMA), 12 waves per workgroup (3 per SIMD, one
+//            workgroup per CU), f16-split MFMA
+// variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch), full 2 KB neighbour records
+// variant 5: the previous default - full neighbour records, register-lean VALU first layer, 12 waves per workgroup
 // variants 2-4 (experiments kept for A/B runs): 4-wave workgroups with prefetch; 4-wave lean; 16-wave lean
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant) {
@@ -1059,8 +1130,13 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
         // small launches (one structure, or the nn = 8/16 layers of a small batch) cannot fill 256 twelve-wave workgroups:
         // the same kernel body in four-wave workgroups spreads them over more CUs
         const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
-        if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
-        else launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+        if (variant == 5) {
+            if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
+            else launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+        } else {
+            if (n_work >= 2048) launch_edge_t<12, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
+            else launch_edge_t<8, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);   // 63 KB of constants: one workgroup per CU
+        }
     }
 }
 

@@ -106,6 +106,25 @@ int32_t put_frags_f16(std::vector<float>& img, const Mat& M, int n_m, int n_kg) 
     memcpy(&img[off], h.data(), h.size() * sizeof(_Float16));
     return (int32_t)off;
 }
+// same hi/lo tables for an operand whose k index is NOT a chained MFMA output but data gathered by the kernel itself: lane
+// (row, kg) feeds k = 32 kgroup + 8 kg + j, i.e. eight CONSECUTIVE input features (one 32-byte gather per lane):
+// [m][kgroup][hi|lo][lane][j] = split(W[16m + (lane&15)][32 kgroup + 8(lane>>4) + j])
+int32_t put_frags_f16_linear(std::vector<float>& img, const Mat& M, int n_m, int n_kg) {
+    std::vector<_Float16> h;
+    for (int m = 0; m < n_m; ++m)
+        for (int kgp = 0; kgp < n_kg; ++kgp)
+            for (int part = 0; part < 2; ++part)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float w = M.get(16 * m + (lane & 15), 32 * kgp + 8 * (lane >> 4) + j);
+                        const _Float16 hi = (_Float16)w;
+                        h.push_back(part == 0 ? hi : (_Float16)(w - (float)hi));
+                    }
+    const size_t off = img.size();
+    img.resize(off + h.size() / 2);
+    memcpy(&img[off], h.data(), h.size() * sizeof(_Float16));
+    return (int32_t)off;
+}
 int32_t put_vec(std::vector<float>& img, const float* src, int n, int pad_to = 0) {
     int32_t off = (int32_t)img.size();
     img.insert(img.end(), src, src + n);
@@ -243,6 +262,12 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
             tmp.clear();
             put_frags_f16(tmp, Wk16, 1, 2);
             std::copy(tmp.begin(), tmp.end(), img.begin() + W.e_lds16 + EL_W3K);
+            // hybrid first layer: the p_j.r block of edge layer 1 (W1[:, 161:193]) applied per edge on the matrix cores
+            Mat W1p(128, 32);
+            for (int f = 0; f < 128; ++f)
+                for (int c = 0; c < 32; ++c) W1p.at(f, c) = W1.get(f, 161 + c);
+            const int32_t off = put_frags_f16_linear(img, W1p, 8, 1);      // appended right behind the 11600-float image
+            if (off != W.e_lds16 + EL_W1P) abort();
         }
         // node kernel: finish (qpm, ppm)
         {

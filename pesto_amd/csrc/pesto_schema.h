@@ -56,9 +56,14 @@ constexpr int EL_BK = EL_B2 + 128;        // 16
 constexpr int EL_B3V = EL_BK + 16;        // 64
 constexpr int EL_WD = EL_B3V + 64;        // 128  (column 0 of edge layer 1: the distance weight)
 constexpr int EDGE_LDS_FLOATS = EL_WD + 128;   // 11600
+// hybrid first layer (e_lds16 image only): f16 hi/lo fragments of W1[:, 161:193] (the p_j.r block), linear-k layout
+// [mb 8][hi|lo][lane][8 halves] (put_frags_f16_linear)
+constexpr int EL_W1P = EDGE_LDS_FLOATS;
+constexpr int EDGE_LDS_FLOATS_HY = EL_W1P + 8 * 2 * 256;   // 15696
 
 // per-atom records written by the node kernel and read by the edge kernel (float counts)
 constexpr int REC_NB = 512;    // [fb 8][g 4][A,C0,C1,C2][r 4]  (p_j itself is gathered from the state array)
+constexpr int REC_A = 128;     // hybrid path: only A_j[f] (natural feature order); the C_j terms are recomputed per edge from p_j
 constexpr int REC_CEN = 528;   // [fb 8][kg 4: G0,G1,G2,U][f 16] = 512, then Q[12] padded to 16
 constexpr int REC_Z = 256;     // Zq[h*32+s] (64), Zp[c][h*32+s] (192)
 struct ModelW {

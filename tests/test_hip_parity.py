@@ -11,12 +11,13 @@ from pesto_amd.config import CONFIGS
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["mfma", "mfma_exact", "v1"])
+@pytest.fixture(params=["mfma", "mfma_records", "mfma_exact", "v1"])
 def impl(request, monkeypatch):
-    """All layer implementations: the shipped MFMA path (big GEMMs on f16-split MFMA), the same kernels on exact fp32
-    MFMA (PESTO_EDGE_VARIANT=1) and the LDS-tiled VALU path (PESTO_IMPL=v1)."""
+    """All layer implementations: the shipped MFMA path (hybrid first layer, big GEMMs on f16-split MFMA), the previous
+    default with full neighbour records (PESTO_EDGE_VARIANT=5), the same kernels on exact fp32 MFMA (PESTO_EDGE_VARIANT=1)
+    and the LDS-tiled VALU path (PESTO_IMPL=v1)."""
     monkeypatch.setenv("PESTO_IMPL", "v1" if request.param == "v1" else "v2")
-    monkeypatch.setenv("PESTO_EDGE_VARIANT", "1" if request.param == "mfma_exact" else "0")
+    monkeypatch.setenv("PESTO_EDGE_VARIANT", {"mfma_exact": "1", "mfma_records": "5"}.get(request.param, "0"))
     return request.param
 
 
