@@ -31,18 +31,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
-// fp32 -> (hi, lo) f16 pair with x = hi + lo to ~2^-21 relative: hi = rtz16(x), lo = rtz16(x - hi) (the residual is
+// fp32 -> (hi, lo) f16 pair with x = hi + lo to ~2^-21 relative: hi = rtz16(x), lo = rn16(x - hi) (the residual is
 // exact in fp32). Two 16-feature blocks (4 + 4 values of this lane) form the 8 k-values one lane feeds to
 // v_mfma_f32_16x16x32_f16. Three MFMAs (hi*hi, lo*hi, hi*lo) then reproduce the fp32 product to ~2^-21.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// lo pair = f16(v0 - hi.lo), f16(v1 - hi.hi): one mixed-precision fma each (fp32 arithmetic on the f16 operand, f16 result,
+// round to nearest) instead of convert + subtract + convert. The compiler folds fma(h, -1, x) back into a subtract, hence asm.
+__device__ __forceinline__ unsigned resid_pack(unsigned hpair, float v0, float v1) {
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hpair), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hpair), "v"(v1));
+    return lo;
+}
 __device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
     const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    u32x4 h, l;
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v[j], v[j + 1]);
-        const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(v[j] - (float)h[0], v[j + 1] - (float)h[1]);
-        hi[j] = (_Float16)h[0]; hi[j + 1] = (_Float16)h[1];
-        lo[j] = (_Float16)l[0]; lo[j + 1] = (_Float16)l[1];
+    for (int j = 0; j < 4; ++j) {
+        h[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * j], v[2 * j + 1]));
+        l[j] = resid_pack(h[j], v[2 * j], v[2 * j + 1]);
     }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
 }
 __device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast<const f16x8*>(p); }
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
@@ -55,9 +65,23 @@ __device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast
 #ifdef PESTO_ABL_NOELU
 __device__ __forceinline__ float elu_f(float x) { return x; }
 #else
-__device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+// ELU(x) = x > 0 ? x : exp(x) - 1 = med3(x, exp(x) - 1, 0): exp(x) - 1 >= x everywhere, so for x > 0 the order is 0 < x <= em1
+// and for x <= 0 it is x <= em1 <= 0. One v_med3_f32 instead of compare + select; exp as v_mul + v_exp_f32 (2^t).
+__device__ __forceinline__ float elu_f(float x) {
+    return __builtin_amdgcn_fmed3f(x, __builtin_amdgcn_exp2f(x * 1.44269504088896340736f) - 1.0f, 0.0f);
+}
 #endif
-__device__ __forceinline__ f32x4 elu4(f32x4 v) { return f32x4{elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3])}; }
+__device__ __forceinline__ f32x4 elu4(f32x4 v) {
+#ifdef PESTO_ABL_NOELU
+    return v;
+#else
+    const f32x4 t = v * 1.44269504088896340736f;        // vector form: the scale and the -1 become packed-f32 ops
+    f32x4 ex = f32x4{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+    ex = ex - 1.0f;
+    return f32x4{__builtin_amdgcn_fmed3f(v[0], ex[0], 0.0f), __builtin_amdgcn_fmed3f(v[1], ex[1], 0.0f),
+                 __builtin_amdgcn_fmed3f(v[2], ex[2], 0.0f), __builtin_amdgcn_fmed3f(v[3], ex[3], 0.0f)};
+#endif
+}
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -522,7 +546,7 @@ __device__ __forceinline__ f32x4 l1_compute(const L1Ops& o, int fb, int g, float
 }
 
 // per-tile addressing: centre record(s), neighbour record of this lane's edge, geometry
-struct TileCtx { const float *cenA, *cenB, *recj; float rx, ry, rz, d, bgA, bgB; };
+struct TileCtx { const float *cenA, *cenB, *recj, *recj_p; float rx, ry, rz, d, bgA, bgB; };
 
 template <int NN, bool HY = false>
 __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1, const EdgeWaveScratch& ws,
@@ -541,23 +565,42 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
 #else
     c.recj = rec_nb + (size_t)ws.nb[row] * (HY ? REC_A : REC_NB);
 #endif
+    c.recj_p = rec_nb + (size_t)ws.nb[16 * t + ((16 * g + e) >> 2)] * (HY ? REC_A : REC_NB);
     return c;
 }
 
 // ---- hybrid first layer: neighbour terms = A_j (gathered, 512 B) + W[:,161:193] (p_j . r) on the matrix cores
 // B operand of the W1P MFMAs for one tile: lane (edge e, kg = g) holds p_j(e) . r_hat for s = 8g .. 8g+7, as f16 hi/lo
 struct TileFeat { f16x8 h, l; };
-__device__ __forceinline__ TileFeat tile_feat(const float* __restrict__ p_state, int nbj, int g, float rx, float ry, float rz) {
-    const float* pj = p_state + (size_t)nbj * 96 + 8 * g;
+// Gathers are issued in a PRODUCER lane layout, lane = 4 * edge + chunk: the four lanes of an edge read 64 contiguous bytes, so
+// a quarter-wave (what the vector L1 processes per pass) touches 4 cache lines instead of 16 - the L1's line-request rate,
+// not bytes or VALU, bounded this kernel. The MFMA operand layout wants lane = 16 * chunk + edge; values move there with
+// ds_bpermute (LDS crossbar, no LDS storage): MFMA lane (e, g) pulls from producer lane 4e + g.
+__device__ __forceinline__ float bperm(int src_byte, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_byte, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ f32x4 to_mfma_lanes(f32x4 v, int lane) {
+    const int src = (4 * (lane & 15) + (lane >> 4)) << 2;
+    return f32x4{bperm(src, v[0]), bperm(src, v[1]), bperm(src, v[2]), bperm(src, v[3])};
+}
+// producer lane (edge ep = lane >> 2, chunk = lane & 3): p_j(ep) . r_hat(ep) for s = 8 chunk .. 8 chunk + 7, split, then transposed
+__device__ __forceinline__ TileFeat tile_feat(const float* __restrict__ p_state, int nb_p, int lane, float rx, float ry, float rz) {
+    const float* pj = p_state + (size_t)nb_p * 96 + 8 * (lane & 3);
     const f32x4 x0 = ld4(pj), x1 = ld4(pj + 4), y0 = ld4(pj + 32), y1 = ld4(pj + 36), z0 = ld4(pj + 64), z1 = ld4(pj + 68);
-    f32x4 a, b;
+    const f32x4 a = x0 * rx + y0 * ry + z0 * rz;          // model_operations.py:115
+    const f32x4 b = x1 * rx + y1 * ry + z1 * rz;
+    f16x8 h, l;
+    split8(a, b, h, l);
+    const int src = (4 * (lane & 15) + (lane >> 4)) << 2;
+    u32x4 hp = __builtin_bit_cast(u32x4, h), lp = __builtin_bit_cast(u32x4, l);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        a[r] = x0[r] * rx + y0[r] * ry + z0[r] * rz;      // model_operations.py:115
-        b[r] = x1[r] * rx + y1[r] * ry + z1[r] * rz;
+    for (int j = 0; j < 4; ++j) {
+        hp[j] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)hp[j]);
+        lp[j] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)lp[j]);
     }
     TileFeat f;
-    split8(a, b, f.h, f.l);
+    f.h = __builtin_bit_cast(f16x8, hp);
+    f.l = __builtin_bit_cast(f16x8, lp);
     return f;
 }
 // h1 of the four feature blocks fb0 .. fb0+3 of one tile
@@ -567,7 +610,7 @@ __device__ __forceinline__ void l1_tile_hy(int fb0, int lane, int g, const TileC
     f32x4 acc[4], a4[4];
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
-        a4[fb] = ld4(tc.recj + (fb0 + fb) * 16 + 4 * g);
+        a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * (lane & 3));     // producer layout: lane = 4 * edge + 16-byte chunk
         acc[fb] = MFMA(tc.cenA[(fb0 + fb) * 64 + lane], tc.bgA, (f32x4{0, 0, 0, 0}));      // sum_c G_i[c] r_c + U_i
         if (NN == 8) acc[fb] = MFMA(tc.cenB[(fb0 + fb) * 64 + lane], tc.bgB, acc[fb]);
     }
@@ -589,8 +632,7 @@ __device__ __forceinline__ void l1_tile_hy(int fb0, int lane, int g, const TileC
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
         const f32x4 w4 = ld4(wd + 16 * (fb0 + fb) + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h1[fb][r] = elu_f(acc[fb][r] + a4[fb][r] + tc.d * w4[r]);
+        h1[fb] = elu4(acc[fb] + to_mfma_lanes(a4[fb], lane) + tc.d * w4);
     }
 }
 
@@ -631,7 +673,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     const float* w2f = sm.w + EL_W2F;
     const float* w3k = sm.w + EL_W3K;
     const float* w3v = sm.w + EL_W3V;
-    const float sdk = sqrtf((float)NK);
+    const float inv_sdk = 1.0f / sqrtf((float)NK);   // logits / sdk (model_operations.py:139-140) as a multiply
 
     // XCD-aware work mapping: workgroup b runs on XCD b % 8 (observed dispatch order; speed only). Each XCD owns
     // one contiguous eighth of the work items, consecutive workgroups of an XCD take consecutive items, so the
@@ -729,7 +771,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 const float* Qv = rec_cen + (size_t)min(c0 + aMine, N1 - 1) * REC_CEN + 512 + (g == 0 ? 0 : 6);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    ws.wts[h * 4 + g][16 * t + e] = (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) / sdk;
+                    ws.wts[h * 4 + g][16 * t + e] = (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) * inv_sdk;
             };
             if (PF) {
                 // tile-batched: the four first-layer blocks of a tile are computed together (VALU phase, independent
@@ -762,7 +804,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     const TileCtx tcc = tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
                     f32x4 h1[4];
                     if (HY) {
-                        const TileFeat tf = tile_feat(p_state, ws.nb[16 * t + e], g, tcc.rx, tcc.ry, tcc.rz);
+                        const int rp = 16 * t + (lane >> 2);
+                        const TileFeat tf = tile_feat(p_state, ws.nb[rp], lane, ws.geo[0][rp], ws.geo[1][rp], ws.geo[2][rp]);
                         l1_tile_hy<NN>(0, lane, g, tcc, tf, sm.w + EL_W1P, sm.w + EL_WD, h1);
                     } else {
                         l1_tile_lean<NN>(0, lane, g, tcc, sm.w + EL_WD, h1);
@@ -812,7 +855,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     s3 = e < 8 ? lane_bcast(sm_, 48) : lane_bcast(sm_, 56);
                 }
                 const float tot = g == 0 ? sm_ : (s1 + s2) + s3;
-                ws.wts[h * 4 + g][16 * t + e] = ex[t] / tot;
+                ws.wts[h * 4 + g][16 * t + e] = ex[t] * __builtin_amdgcn_rcpf(tot);
                 // centre-level sum of the part-2 weights (what multiplies p_i in Zp): written by the part-2 lanes
                 if (g == 2 && (NN == 8 ? (e & 7) == 0 : e == 0) && (t % TPC) == 0) {
                     const int a = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
@@ -867,7 +910,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 for (int fbl = 0; fbl < 4; ++fbl)
                     h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
             } else if (HY) {
-                const TileFeat tf = tile_feat(p_state, ws.nb[16 * t + e], g, tc.rx, tc.ry, tc.rz);
+                const int rp = 16 * t + (lane >> 2);
+                const TileFeat tf = tile_feat(p_state, ws.nb[rp], lane, ws.geo[0][rp], ws.geo[1][rp], ws.geo[2][rp]);
                 l1_tile_hy<NN>(4, lane, g, tc, tf, sm.w + EL_W1P, sm.w + EL_WD, h1);
             } else {
                 l1_tile_lean<NN>(4, lane, g, tc, sm.w + EL_WD, h1);
