@@ -571,7 +571,6 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
 
 // ---- hybrid first layer: neighbour terms = A_j (gathered, 512 B) + W[:,161:193] (p_j . r) on the matrix cores
 // B operand of the W1P MFMAs for one tile: lane (edge e, kg = g) holds p_j(e) . r_hat for s = 8g .. 8g+7, as f16 hi/lo
-struct TileFeat { f16x8 h, l; };
 // Gathers are issued in a PRODUCER lane layout, lane = 4 * edge + chunk: the four lanes of an edge read 64 contiguous bytes, so
 // a quarter-wave (what the vector L1 processes per pass) touches 4 cache lines instead of 16 - the L1's line-request rate,
 // not bytes or VALU, bounded this kernel. The MFMA operand layout wants lane = 16 * chunk + edge; values move there with
@@ -583,36 +582,47 @@ __device__ __forceinline__ f32x4 to_mfma_lanes(f32x4 v, int lane) {
     const int src = (4 * (lane & 15) + (lane >> 4)) << 2;
     return f32x4{bperm(src, v[0]), bperm(src, v[1]), bperm(src, v[2]), bperm(src, v[3])};
 }
-// producer lane (edge ep = lane >> 2, chunk = lane & 3): p_j(ep) . r_hat(ep) for s = 8 chunk .. 8 chunk + 7, split, then transposed
-__device__ __forceinline__ TileFeat tile_feat(const float* __restrict__ p_state, int nb_p, int lane, float rx, float ry, float rz) {
-    const float* pj = p_state + (size_t)nb_p * 96 + 8 * (lane & 3);
+// h1 of the four feature blocks fb0 .. fb0+3 of tile t. ALL global loads of the tile (p_j rows, A_j chunks, centre record
+// columns) are issued up front, ahead of a scheduling barrier: left to itself the scheduler issued the A_j / centre loads one
+// block at a time, each followed by a full vmcnt(0) wait - five serialized memory round trips per tile.
+template <int NN>
+__device__ __forceinline__ void l1_tile_hy(int fb0, int t, int lane, int g, const TileCtx& tc, const EdgeWaveScratch& ws,
+                                           const float* __restrict__ p_state, const float* __restrict__ w1p,
+                                           const float* __restrict__ wd, f32x4* h1) {
+    // producer lane (edge ep = lane >> 2, chunk = lane & 3)
+    const int rp = 16 * t + (lane >> 2);
+    const float* pj = p_state + (size_t)ws.nb[rp] * 96 + 8 * (lane & 3);
     const f32x4 x0 = ld4(pj), x1 = ld4(pj + 4), y0 = ld4(pj + 32), y1 = ld4(pj + 36), z0 = ld4(pj + 64), z1 = ld4(pj + 68);
-    const f32x4 a = x0 * rx + y0 * ry + z0 * rz;          // model_operations.py:115
+    f32x4 a4[4];
+    float cA[4], cB[4];
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * (lane & 3));
+        cA[fb] = tc.cenA[(fb0 + fb) * 64 + lane];
+        cB[fb] = NN == 8 ? tc.cenB[(fb0 + fb) * 64 + lane] : 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // p_j(ep) . r_hat(ep) for s = 8 chunk .. 8 chunk + 7 (model_operations.py:115), split, moved to the MFMA lane layout
+    const float rx = ws.geo[0][rp], ry = ws.geo[1][rp], rz = ws.geo[2][rp];
+    const f32x4 a = x0 * rx + y0 * ry + z0 * rz;
     const f32x4 b = x1 * rx + y1 * ry + z1 * rz;
-    f16x8 h, l;
-    split8(a, b, h, l);
+    f16x8 fh, fl;
+    split8(a, b, fh, fl);
     const int src = (4 * (lane & 15) + (lane >> 4)) << 2;
-    u32x4 hp = __builtin_bit_cast(u32x4, h), lp = __builtin_bit_cast(u32x4, l);
+    u32x4 hp = __builtin_bit_cast(u32x4, fh), lp = __builtin_bit_cast(u32x4, fl);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         hp[j] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)hp[j]);
         lp[j] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)lp[j]);
     }
-    TileFeat f;
-    f.h = __builtin_bit_cast(f16x8, hp);
-    f.l = __builtin_bit_cast(f16x8, lp);
-    return f;
-}
-// h1 of the four feature blocks fb0 .. fb0+3 of one tile
-template <int NN>
-__device__ __forceinline__ void l1_tile_hy(int fb0, int lane, int g, const TileCtx& tc, const TileFeat& tf, const float* __restrict__ w1p,
-                                           const float* __restrict__ wd, f32x4* h1) {
-    f32x4 acc[4], a4[4];
+    fh = __builtin_bit_cast(f16x8, hp);
+    fl = __builtin_bit_cast(f16x8, lp);
+    f32x4 acc[4];
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
-        a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * (lane & 3));     // producer layout: lane = 4 * edge + 16-byte chunk
-        acc[fb] = MFMA(tc.cenA[(fb0 + fb) * 64 + lane], tc.bgA, (f32x4{0, 0, 0, 0}));      // sum_c G_i[c] r_c + U_i
-        if (NN == 8) acc[fb] = MFMA(tc.cenB[(fb0 + fb) * 64 + lane], tc.bgB, acc[fb]);
+        a4[fb] = to_mfma_lanes(a4[fb], lane);
+        acc[fb] = MFMA(cA[fb], tc.bgA, (f32x4{0, 0, 0, 0}));      // sum_c G_i[c] r_c + U_i
+        if (NN == 8) acc[fb] = MFMA(cB[fb], tc.bgB, acc[fb]);
     }
 #pragma unroll
     for (int m0 = 0; m0 < 4; m0 += 2) {
@@ -623,16 +633,16 @@ __device__ __forceinline__ void l1_tile_hy(int fb0, int lane, int g, const TileC
             wh[ml] = ld8h(fr); wl[ml] = ld8h(fr + 256);
         }
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wh[ml], tf.h, acc[m0 + ml]);
+        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wh[ml], fh, acc[m0 + ml]);
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wh[ml], tf.l, acc[m0 + ml]);
+        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wh[ml], fl, acc[m0 + ml]);
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wl[ml], tf.h, acc[m0 + ml]);
+        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wl[ml], fh, acc[m0 + ml]);
     }
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
         const f32x4 w4 = ld4(wd + 16 * (fb0 + fb) + 4 * g);
-        h1[fb] = elu4(acc[fb] + to_mfma_lanes(a4[fb], lane) + tc.d * w4);
+        h1[fb] = elu4(acc[fb] + a4[fb] + tc.d * w4);
     }
 }
 
@@ -804,9 +814,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     const TileCtx tcc = tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
                     f32x4 h1[4];
                     if (HY) {
-                        const int rp = 16 * t + (lane >> 2);
-                        const TileFeat tf = tile_feat(p_state, ws.nb[rp], lane, ws.geo[0][rp], ws.geo[1][rp], ws.geo[2][rp]);
-                        l1_tile_hy<NN>(0, lane, g, tcc, tf, sm.w + EL_W1P, sm.w + EL_WD, h1);
+                        l1_tile_hy<NN>(0, t, lane, g, tcc, ws, p_state, sm.w + EL_W1P, sm.w + EL_WD, h1);
                     } else {
                         l1_tile_lean<NN>(0, lane, g, tcc, sm.w + EL_WD, h1);
                     }
@@ -910,9 +918,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 for (int fbl = 0; fbl < 4; ++fbl)
                     h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
             } else if (HY) {
-                const int rp = 16 * t + (lane >> 2);
-                const TileFeat tf = tile_feat(p_state, ws.nb[rp], lane, ws.geo[0][rp], ws.geo[1][rp], ws.geo[2][rp]);
-                l1_tile_hy<NN>(4, lane, g, tc, tf, sm.w + EL_W1P, sm.w + EL_WD, h1);
+                l1_tile_hy<NN>(4, t, lane, g, tc, ws, p_state, sm.w + EL_W1P, sm.w + EL_WD, h1);
             } else {
                 l1_tile_lean<NN>(4, lane, g, tc, sm.w + EL_WD, h1);
             }
