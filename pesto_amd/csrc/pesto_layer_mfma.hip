@@ -582,30 +582,39 @@ __device__ __forceinline__ f32x4 to_mfma_lanes(f32x4 v, int lane) {
     const int src = (4 * (lane & 15) + (lane >> 4)) << 2;
     return f32x4{bperm(src, v[0]), bperm(src, v[1]), bperm(src, v[2]), bperm(src, v[3])};
 }
-// h1 of the four feature blocks fb0 .. fb0+3 of tile t. ALL global loads of the tile (p_j rows, A_j chunks, centre record
-// columns) are issued up front, ahead of a scheduling barrier: left to itself the scheduler issued the A_j / centre loads one
-// block at a time, each followed by a full vmcnt(0) wait - five serialized memory round trips per tile.
+// First layer of the four feature blocks fb0 .. fb0+3 of tile t, in three steps so that the caller can software-pipeline:
+//   l1_issue : ALL global loads of the tile (p_j rows, A_j chunks, centre record columns) issued together - left to itself the
+//              scheduler issued the A_j / centre loads one block at a time, each followed by a full vmcnt(0) wait (five
+//              serialized memory round trips per tile);
+//   l1_head  : p_j . r_hat -> f16 hi/lo -> MFMA lane layout, A_j chunks -> MFMA lane layout, centre MFMAs (consumes the raw loads);
+//   l1_tail  : the W1P MFMAs, distance term, ELU.
+struct L1Raw { f32x4 x0, x1, y0, y1, z0, z1, a4[4]; float cA[4], cB[4]; };
+struct L1Head { f16x8 fh, fl; f32x4 a4[4], acc[4]; float d; };
+
 template <int NN>
-__device__ __forceinline__ void l1_tile_hy(int fb0, int t, int lane, int g, const TileCtx& tc, const EdgeWaveScratch& ws,
-                                           const float* __restrict__ p_state, const float* __restrict__ w1p,
-                                           const float* __restrict__ wd, f32x4* h1) {
-    // producer lane (edge ep = lane >> 2, chunk = lane & 3)
-    const int rp = 16 * t + (lane >> 2);
+__device__ __forceinline__ L1Raw l1_issue(int fb0, int t, int lane, const TileCtx& tc, const EdgeWaveScratch& ws,
+                                          const float* __restrict__ p_state) {
+    L1Raw r;
+    const int rp = 16 * t + (lane >> 2);               // producer lane: edge rp, 16-byte chunk lane & 3
     const float* pj = p_state + (size_t)ws.nb[rp] * 96 + 8 * (lane & 3);
-    const f32x4 x0 = ld4(pj), x1 = ld4(pj + 4), y0 = ld4(pj + 32), y1 = ld4(pj + 36), z0 = ld4(pj + 64), z1 = ld4(pj + 68);
-    f32x4 a4[4];
-    float cA[4], cB[4];
+    r.x0 = ld4(pj); r.x1 = ld4(pj + 4); r.y0 = ld4(pj + 32); r.y1 = ld4(pj + 36); r.z0 = ld4(pj + 64); r.z1 = ld4(pj + 68);
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
-        a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * (lane & 3));
-        cA[fb] = tc.cenA[(fb0 + fb) * 64 + lane];
-        cB[fb] = NN == 8 ? tc.cenB[(fb0 + fb) * 64 + lane] : 0.0f;
+        r.a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * (lane & 3));
+        r.cA[fb] = tc.cenA[(fb0 + fb) * 64 + lane];
+        r.cB[fb] = NN == 8 ? tc.cenB[(fb0 + fb) * 64 + lane] : 0.0f;
     }
-    __builtin_amdgcn_sched_barrier(0);
+    return r;
+}
+
+template <int NN>
+__device__ __forceinline__ L1Head l1_head(const L1Raw& r, int t, int lane, const TileCtx& tc, const EdgeWaveScratch& ws) {
+    L1Head o;
+    const int rp = 16 * t + (lane >> 2);
     // p_j(ep) . r_hat(ep) for s = 8 chunk .. 8 chunk + 7 (model_operations.py:115), split, moved to the MFMA lane layout
     const float rx = ws.geo[0][rp], ry = ws.geo[1][rp], rz = ws.geo[2][rp];
-    const f32x4 a = x0 * rx + y0 * ry + z0 * rz;
-    const f32x4 b = x1 * rx + y1 * ry + z1 * rz;
+    const f32x4 a = r.x0 * rx + r.y0 * ry + r.z0 * rz;
+    const f32x4 b = r.x1 * rx + r.y1 * ry + r.z1 * rz;
     f16x8 fh, fl;
     split8(a, b, fh, fl);
     const int src = (4 * (lane & 15) + (lane >> 4)) << 2;
@@ -615,15 +624,20 @@ __device__ __forceinline__ void l1_tile_hy(int fb0, int t, int lane, int g, cons
         hp[j] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)hp[j]);
         lp[j] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)lp[j]);
     }
-    fh = __builtin_bit_cast(f16x8, hp);
-    fl = __builtin_bit_cast(f16x8, lp);
-    f32x4 acc[4];
+    o.fh = __builtin_bit_cast(f16x8, hp);
+    o.fl = __builtin_bit_cast(f16x8, lp);
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
-        a4[fb] = to_mfma_lanes(a4[fb], lane);
-        acc[fb] = MFMA(cA[fb], tc.bgA, (f32x4{0, 0, 0, 0}));      // sum_c G_i[c] r_c + U_i
-        if (NN == 8) acc[fb] = MFMA(cB[fb], tc.bgB, acc[fb]);
+        o.a4[fb] = to_mfma_lanes(r.a4[fb], lane);
+        o.acc[fb] = MFMA(r.cA[fb], tc.bgA, (f32x4{0, 0, 0, 0}));      // sum_c G_i[c] r_c + U_i
+        if (NN == 8) o.acc[fb] = MFMA(r.cB[fb], tc.bgB, o.acc[fb]);
     }
+    o.d = tc.d;
+    return o;
+}
+
+__device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, const float* __restrict__ w1p, const float* __restrict__ wd,
+                                        f32x4* h1) {
 #pragma unroll
     for (int m0 = 0; m0 < 4; m0 += 2) {
         f16x8 wh[2], wl[2];
@@ -633,16 +647,16 @@ __device__ __forceinline__ void l1_tile_hy(int fb0, int t, int lane, int g, cons
             wh[ml] = ld8h(fr); wl[ml] = ld8h(fr + 256);
         }
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wh[ml], fh, acc[m0 + ml]);
+        for (int ml = 0; ml < 2; ++ml) o.acc[m0 + ml] = MFMA16(wh[ml], o.fh, o.acc[m0 + ml]);
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wh[ml], fl, acc[m0 + ml]);
+        for (int ml = 0; ml < 2; ++ml) o.acc[m0 + ml] = MFMA16(wh[ml], o.fl, o.acc[m0 + ml]);
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) acc[m0 + ml] = MFMA16(wl[ml], fh, acc[m0 + ml]);
+        for (int ml = 0; ml < 2; ++ml) o.acc[m0 + ml] = MFMA16(wl[ml], o.fh, o.acc[m0 + ml]);
     }
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
         const f32x4 w4 = ld4(wd + 16 * (fb0 + fb) + 4 * g);
-        h1[fb] = elu4(acc[fb] + a4[fb] + tc.d * w4);
+        h1[fb] = elu4(o.acc[fb] + o.a4[fb] + o.d * w4);
     }
 }
 
@@ -809,16 +823,32 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     keys_of_tile(t, h1);
                 }
             } else {
+                if (HY) {
+                    // software pipeline over the four tiles: the NEXT tile's gathers are issued as soon as this tile's raw loads
+                    // have been consumed, and fly during this tile's MFMA / ELU / key-network work
+                    TileCtx tcc = tile_ctx<NN, HY>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
+                    L1Raw raw = l1_issue<NN>(0, 0, lane, tcc, ws, p_state);
 #pragma unroll 1
-                for (int t = 0; t < 4; ++t) {   // register-lean: rolled loop, operands fetched block by block
-                    const TileCtx tcc = tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
-                    f32x4 h1[4];
-                    if (HY) {
-                        l1_tile_hy<NN>(0, t, lane, g, tcc, ws, p_state, sm.w + EL_W1P, sm.w + EL_WD, h1);
-                    } else {
-                        l1_tile_lean<NN>(0, lane, g, tcc, sm.w + EL_WD, h1);
+                    for (int t = 0; t < 4; ++t) {
+                        L1Head hd = l1_head<NN>(raw, t, lane, tcc, ws);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (t < 3) {
+                            tcc = tile_ctx<NN, HY>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
+                            raw = l1_issue<NN>(0, t + 1, lane, tcc, ws, p_state);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4 h1[4];
+                        l1_tail(hd, 0, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1);
+                        keys_of_tile(t, h1);
                     }
-                    keys_of_tile(t, h1);
+                } else {
+#pragma unroll 1
+                    for (int t = 0; t < 4; ++t) {   // register-lean: rolled loop, operands fetched block by block
+                        const TileCtx tcc = tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
+                        f32x4 h1[4];
+                        l1_tile_lean<NN>(0, lane, g, tcc, sm.w + EL_WD, h1);
+                        keys_of_tile(t, h1);
+                    }
                 }
             }
         }
@@ -918,7 +948,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 for (int fbl = 0; fbl < 4; ++fbl)
                     h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
             } else if (HY) {
-                l1_tile_hy<NN>(4, t, lane, g, tc, ws, p_state, sm.w + EL_W1P, sm.w + EL_WD, h1);
+                const L1Raw raw = l1_issue<NN>(4, t, lane, tc, ws, p_state);
+                __builtin_amdgcn_sched_barrier(0);
+                L1Head hd = l1_head<NN>(raw, t, lane, tc, ws);
+                l1_tail(hd, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1);
             } else {
                 l1_tile_lean<NN>(4, lane, g, tc, sm.w + EL_WD, h1);
             }
