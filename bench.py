@@ -33,13 +33,14 @@ def layer_flops_per_atom(nn):
 
 def executed_mfma_flops(config, n1):
     """FLOPs the MFMA pipes actually execute per forward on the shipped path (f16 hi/lo split: 3 products per GEMM).
-    Edge kernel per 16-edge tile: 8 (16 when nn = 8) fp32 16x16x4 MFMAs (1,024 MAC) for the centre terms + 66 f16 16x16x32
-    MFMAs (8,192 MAC); node kernel per 16 atoms: 321 f16 MFMAs (the last launch only runs its 60-MFMA finish half)."""
+    Edge kernel per 16-edge tile: 8 (16 when nn = 8) fp32 16x16x4 MFMAs (1,024 MAC) for the centre terms + 90 f16 16x16x32
+    MFMAs (8,192 MAC: 24 for the per-edge p_j.r block of layer 1, 18 key networks, 48 value network); node kernel per 16
+    atoms: 249 f16 MFMAs (the last launch only runs its 60-MFMA finish half)."""
     total = 0.0
     for l in config["sum"]:
         tiles = n1 * l["nn"] / 16.0
-        total += tiles * ((16 if l["nn"] == 8 else 8) * 1024 + 66 * 8192) * 2.0
-        total += n1 / 16.0 * 321 * 8192 * 2.0
+        total += tiles * ((16 if l["nn"] == 8 else 8) * 1024 + 90 * 8192) * 2.0
+        total += n1 / 16.0 * 249 * 8192 * 2.0
     return total
 
 
@@ -236,8 +237,8 @@ def main():
                          "layers_ms": layers_ms, "forward_ms": fwd_ms,
                          "executed_mfma_tflops": executed_mfma_flops(config, n1) / (layers_ms * 1e-3) / 1e12,
                          "note": "achieved = reference-formulation FLOPs (SURVEY 8d) of all layer launches of one forward / their "
-                                 "HIP-event time; peak = dense fp32 MFMA. The kernels execute ~3x fewer FLOPs (first edge Linear "
-                                 "folded per atom) and run the big GEMMs as f16 hi/lo split MFMA, so frac can exceed 1; "
+                                 "HIP-event time; peak = dense fp32 MFMA. The kernels execute ~2.5x fewer FLOPs (most of the first edge "
+                                 "Linear folded per atom) and run the big GEMMs as f16 hi/lo split MFMA, so frac can exceed 1; "
                                  "traffic = HBM-side bytes per forward from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE)"},
             "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": achieved_gbs / PEAK_HBM_GBS, "bytes_per_forward": gbytes,

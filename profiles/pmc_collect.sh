@@ -7,6 +7,7 @@ TAG=${1:-run}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
+mkdir -p $R/gpurun_out/pmc_$TAG
 CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-latency"
 i=0
 for SET in \
@@ -17,7 +18,7 @@ for SET in \
   "WRITE_SIZE GRBM_GUI_ACTIVE"
 do
   i=$((i+1))
-  rocprofv3 --pmc $SET -d $R/gpurun_out/pmc_$TAG/p$i -o pmc --output-format csv -- $CMD > $R/gpurun_out/pmc_$TAG/p$i.log 2>&1 || echo "pass $i failed"
+  timeout 240 rocprofv3 --pmc $SET -d $R/gpurun_out/pmc_$TAG/p$i -o pmc --output-format csv -- $CMD > $R/gpurun_out/pmc_$TAG/p$i.log 2>&1 || echo "pass $i failed"
 done
 python - "$R/gpurun_out/pmc_$TAG" <<'PY'
 import csv, glob, sys, collections

@@ -19,7 +19,7 @@ for SET in \
   "TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum"
 do
   i=$((i+1))
-  rocprofv3 --pmc $SET -d $OUT/p$i -o pmc --output-format csv -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i failed: $SET"
+  timeout 240 rocprofv3 --pmc $SET -d $OUT/p$i -o pmc --output-format csv -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i failed: $SET"
 done
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections
