@@ -61,7 +61,7 @@ struct pesto_model {
     DevBuf rec_nb, rec_cen, zrec;          // MFMA path: per-atom neighbour / centre records and attention sums
     int impl = 2;                          // 2 = MFMA layer (default), 1 = LDS-tiled VALU layer (PESTO_IMPL=v1)
     int edge_blocks = 512;                 // persistent workgroups of the edge kernel (2 per CU)
-    int edge_variant = 0;                  // PESTO_EDGE_VARIANT: 0 = 4 waves/WG + prefetch, 1 = 12 waves/WG, 2 = 16 waves/WG
+    int edge_variant = 0;                  // PESTO_EDGE_VARIANT: 0 = hybrid f16-split (shipped), 1 = exact fp32 MFMA, 5 = full-record f16-split
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     DevBuf knn_off;                       // structure offsets of the last pesto_knn_collate call
     DevBuf dmax, roa_f;                   // per-frame max(D) words; residue column per atom of a frame batch
@@ -211,7 +211,7 @@ int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weight
     m->device = device;
     m->img = build_device_image(*cfg, weights);
     if (const char* impl = getenv("PESTO_IMPL")) m->impl = (strcmp(impl, "v1") == 0 || strcmp(impl, "1") == 0) ? 1 : 2;
-    if (const char* ev = getenv("PESTO_EDGE_VARIANT")) m->edge_variant = atoi(ev);
+    if (const char* ev = getenv("PESTO_EDGE_VARIANT")) { const int v = atoi(ev); m->edge_variant = (v == 1 || v == 5) ? v : 0; }
     if (const char* eb = getenv("PESTO_EDGE_BLOCKS")) { int v = atoi(eb); if (v > 0) m->edge_blocks = v; }
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&m->W, m->img.data.size() * sizeof(float));

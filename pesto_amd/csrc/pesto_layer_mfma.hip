@@ -1201,25 +1201,20 @@ static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int 
 // variant 0 (default): hybrid first layer (A_j record + per-edge p_j.r block on MFMA), 12 waves per workgroup (3 per SIMD, one
 //            workgroup per CU), f16-split MFMA
 // variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch), full 2 KB neighbour records
-// variant 5: the previous default - full neighbour records, register-lean VALU first layer, 12 waves per workgroup
-// variants 2-4 (experiments kept for A/B runs): 4-wave workgroups with prefetch; 4-wave lean; 16-wave lean
+// variant 5: the previous default - full neighbour records, register-lean VALU first layer, f16-split MFMA, 12 waves per workgroup
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant) {
-    if (variant == 1) launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
-    else if (variant == 2) launch_edge_t<4, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
-    else if (variant == 3) launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
-    else if (variant == 4) launch_edge_t<16, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
-    else {
-        // small launches (one structure, or the nn = 8/16 layers of a small batch) cannot fill 256 twelve-wave workgroups:
-        // the same kernel body in four-wave workgroups spreads them over more CUs
-        const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
-        if (variant == 5) {
-            if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
-            else launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
-        } else {
-            if (n_work >= 2048) launch_edge_t<12, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
-            else launch_edge_t<8, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);   // 63 KB of constants: one workgroup per CU
-        }
+    // small launches (one structure, or the nn = 8/16 layers of a small batch) cannot fill 256 twelve-wave workgroups:
+    // the same kernel body in smaller workgroups spreads them over more CUs
+    const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
+    if (variant == 1) {
+        launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+    } else if (variant == 5) {
+        if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
+        else launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+    } else {
+        if (n_work >= 2048) launch_edge_t<12, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
+        else launch_edge_t<8, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);   // 63 KB of constants: one workgroup per CU
     }
 }
 
