@@ -87,6 +87,17 @@ int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_
                          const void* ids_topk, int32_t ids_kind, const float* q0, const int32_t* res_of_atom,
                          float* z_out, int32_t frames_per_launch, int32_t ptr_kind, void* stream);
 
+/* replaces: collate_batch_features (src/dataset.py:91-112) + Model.forward for a LIST of structures - the bulk drivers' loop
+ * (apply_model.ipynb:139-167, interfaceome/apply_model.py:57-82) with several structures per launch.
+ * HOST pointers, one entry per structure b: X[b] float32 [N_b,3]; ids_topk0[b] [N_b,k_b] 0-BASED within the structure, as
+ * extract_topology returns them (k_b = min(64, N_b)); q0[b] [N_b,n0]; res_of_atom[b] int32 [N_b] (column of the structure's
+ * own mask, R_b residues); z_out[b] float32 [R_b,n_out]. The arrays are copied back to back and collated ON THE DEVICE
+ * (offset + 1-based ids zero-padded to 64 columns, residue columns offset); the result is exactly the reference's forward on
+ * the collated batch (one global max(D), padding wraps to the last atom of the batch). Returns after every z_out[b] is filled. */
+int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, const int64_t* R, const int32_t* k,
+                        const float* const* X, const void* const* ids_topk0, int32_t ids_kind, const float* const* q0,
+                        const int32_t* const* res_of_atom, float* const* z_out, void* stream);
+
 /* bytes of device workspace a batch of (N, R) needs (ownership: SURVEY 8b) */
 int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* bytes);
 

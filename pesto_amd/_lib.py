@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "pesto_last_error", "pesto_blob_size", "pesto_create", "pesto_destroy", "pesto_forward",
     "pesto_workspace_bytes", "pesto_synchronize", "pesto_set_timing", "pesto_get_timing",
     "pesto_stage_embed", "pesto_stage_unpack", "pesto_stage_layer", "pesto_stage_pool", "pesto_knn_collate",
-    "pesto_forward_frames", "pesto_postprocess",
+    "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch",
 ]
 
 _lib = None
@@ -81,6 +81,7 @@ def load():
     lib.pesto_destroy.argtypes = [c_p]
     lib.pesto_forward.argtypes = [c_p, i64, i64, i32, c_p, c_p, i32, c_p, c_p, c_p, i32, c_p]
     lib.pesto_forward_frames.argtypes = [c_p, i64, i64, i32, i64, c_p, i64, i64, c_p, i32, c_p, c_p, c_p, i32, i32, c_p]
+    lib.pesto_forward_batch.argtypes = [c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p, c_p, c_p]
     lib.pesto_postprocess.argtypes = [c_p, i64, i64, c_p, c_p, c_p, c_p, i32, c_p]
     lib.pesto_workspace_bytes.argtypes = [c_p, i64, i64, P(i64)]
     lib.pesto_synchronize.argtypes = [c_p]

@@ -64,6 +64,7 @@ struct pesto_model {
     int edge_variant = 0;                  // PESTO_EDGE_VARIANT: 0 = hybrid f16-split (shipped), 1 = exact fp32 MFMA, 5 = full-record f16-split
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     DevBuf knn_off;                       // structure offsets of the last pesto_knn_collate call
+    DevBuf col_meta, col_ids, col_roa;    // pesto_forward_batch: per-structure table, collated ids / residue columns
     DevBuf dmax, roa_f;                   // per-frame max(D) words; residue column per atom of a frame batch
     std::vector<float> pack;              // host packing buffer for strided host frames
     // state left by pesto_stage_unpack for pesto_stage_layer
@@ -235,7 +236,7 @@ int pesto_destroy(pesto_model* m) {
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
-                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f})
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa})
         b->release();
     delete m;
     return 0;
@@ -350,6 +351,53 @@ int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_
         if (int rc = check_device_flag(m, st)) return rc;   // synchronises: staging buffers are free for the next chunk
     }
     return 0;
+}
+
+int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, const int64_t* R, const int32_t* k, const float* const* X,
+                        const void* const* ids_topk0, int32_t ids_kind, const float* const* q0, const int32_t* const* res_of_atom,
+                        float* const* z_out, void* stream) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (n_struct < 1 || !N || !R || !k || !X || !ids_topk0 || !q0 || !res_of_atom || !z_out) return fail(PESTO_ERR_INVALID, "bad arguments");
+    if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
+    struct Meta { int off, roff, n, r, k; long long idoff; };
+    std::vector<Meta> meta((size_t)n_struct);
+    int64_t NT = 0, RT = 0, IT = 0;
+    for (int b = 0; b < n_struct; ++b) {
+        if (N[b] < 1 || R[b] < 1 || R[b] > N[b] || k[b] < 1 || k[b] > KMAX || !X[b] || !ids_topk0[b] || !q0[b] || !res_of_atom[b] || !z_out[b])
+            return fail(PESTO_ERR_INVALID, "structure %d: bad sizes or null buffer (N=%lld R=%lld k=%d)", b, (long long)N[b], (long long)R[b], k[b]);
+        meta[b] = Meta{(int)NT, (int)RT, (int)N[b], (int)R[b], k[b], (long long)IT};
+        NT += N[b]; RT += R[b]; IT += N[b] * k[b];
+        if (NT > 0x7ffffff0 / 96) return fail(PESTO_ERR_INVALID, "batch too large");
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    if (int rc = ensure_workspace(m, NT, RT)) return rc;
+    const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
+    const int n0 = m->cfg.n0, n_out = m->cfg.n_out;
+    if (m->in_X.ensure((size_t)NT * 12) || m->in_ids.ensure((size_t)IT * id_sz) || m->in_q0.ensure((size_t)NT * n0 * 4) ||
+        m->in_roa.ensure((size_t)NT * 4) || m->col_meta.ensure(meta.size() * sizeof(Meta)) || m->col_ids.ensure((size_t)NT * KMAX * 4) ||
+        m->col_roa.ensure((size_t)NT * 4))
+        return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
+    HIP_TRY(hipMemcpyAsync(m->col_meta.p, meta.data(), meta.size() * sizeof(Meta), hipMemcpyHostToDevice, st));
+    for (int b = 0; b < n_struct; ++b) {       // per-structure arrays land back to back: the concatenations of dataset.py:93-94
+        const Meta& mb = meta[b];
+        HIP_TRY(hipMemcpyAsync(m->in_X.as<float>() + (size_t)mb.off * 3, X[b], (size_t)mb.n * 12, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((char*)m->in_ids.p + (size_t)mb.idoff * id_sz, ids_topk0[b], (size_t)mb.n * mb.k * id_sz, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(m->in_q0.as<float>() + (size_t)mb.off * n0, q0[b], (size_t)mb.n * n0 * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(m->in_roa.as<int>() + mb.off, res_of_atom[b], (size_t)mb.n * 4, hipMemcpyHostToDevice, st));
+    }
+    launch_collate(st, (int)NT, n_struct, m->col_meta.p, m->in_ids.p, ids_kind, m->in_roa.as<int>(), m->col_ids.as<int>(), m->col_roa.as<int>(),
+                   err_ptr(m));
+    HIP_TRY(hipGetLastError());
+    if (int rc = check_device_flag(m, st)) return rc;      // bad ids / residue columns are reported before the forward runs
+    FwdArgs a;
+    a.N = NT; a.R = RT; a.F = 1; a.k = KMAX; a.X = m->in_X.as<float>(); a.xs_frame = 3 * NT; a.xs_atom = 3;
+    a.ids = m->col_ids.p; a.ids_kind = PESTO_IDS_INT32; a.q0 = m->in_q0.as<float>(); a.roa = m->col_roa.as<int>(); a.z_out = m->z.as<float>();
+    if (int rc = run_forward(m, st, a)) return rc;
+    for (int b = 0; b < n_struct; ++b)
+        HIP_TRY(hipMemcpyAsync(z_out[b], m->z.as<float>() + (size_t)meta[b].roff * n_out, (size_t)meta[b].r * n_out * 4, hipMemcpyDeviceToHost, st));
+    return check_device_flag(m, st);   // synchronises
 }
 
 int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,

@@ -594,6 +594,45 @@ __global__ __launch_bounds__(256) void k_knn_collate(int n_total, int n_struct, 
     if (lane < KMAX) ids_out[(size_t)i * KMAX + lane] = (IdT)id;
 }
 
+// ------------------------------------------------------------------------------------------------ device-side collate
+// collate_batch_features (src/dataset.py:100-110) for per-structure arrays already copied to the device back to back:
+// ids_out[i][c] = c < k_b ? ids_raw_b[i - off_b][c] + off_b + 1 : 0 (1-based batch-global, zero padded to KMAX columns) and
+// roa_out[i] = roa_raw[i] + roff_b. meta[b] = {off_b, roff_b, N_b, R_b, k_b, idoff_b (element offset of the ragged ids)}.
+struct CollateMeta { int off, roff, n, r, k; long long idoff; };
+template <typename IdT>
+__global__ __launch_bounds__(256) void k_collate(int n_total, int n_struct, const CollateMeta* __restrict__ meta, const IdT* __restrict__ ids_raw,
+                                                 const int* __restrict__ roa_raw, int* __restrict__ ids_out, int* __restrict__ roa_out,
+                                                 int* __restrict__ err_flag) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)n_total * KMAX) return;
+    const int i = (int)(e >> 6), c = (int)(e & 63);
+    int lo = 0, hi = n_struct;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (meta[mid].off <= i) lo = mid; else hi = mid; }
+    const CollateMeta mb = meta[lo];
+    long long id = 0;
+    if (c < mb.k) {
+        id = (long long)ids_raw[mb.idoff + (long long)(i - mb.off) * mb.k + c];
+        if (id < 0 || id >= mb.n) { atomicOr(err_flag, 1); id = 0; } else id += mb.off + 1;
+    }
+    ids_out[e] = (int)id;
+    if (c == 0) {
+        int r = roa_raw[i];
+        if (r < 0 || r >= mb.r) { atomicOr(err_flag, 2); r = 0; }
+        roa_out[i] = r + mb.roff;
+    }
+}
+
+void launch_collate(hipStream_t st, int n_total, int n_struct, const void* meta, const void* ids_raw, int ids_kind, const int* roa_raw,
+                    int* ids_out, int* roa_out, int* err_flag) {
+    const dim3 grid((unsigned)(((int64_t)n_total * KMAX + 255) / 256)), block(256);
+    if (ids_kind == PESTO_IDS_INT64)
+        hipLaunchKernelGGL(k_collate<long long>, grid, block, 0, st, n_total, n_struct, (const CollateMeta*)meta, (const long long*)ids_raw, roa_raw,
+                           ids_out, roa_out, err_flag);
+    else
+        hipLaunchKernelGGL(k_collate<int>, grid, block, 0, st, n_total, n_struct, (const CollateMeta*)meta, (const int*)ids_raw, roa_raw, ids_out,
+                           roa_out, err_flag);
+}
+
 // ------------------------------------------------------------------------------------------------ post-processing
 // p = sigmoid(z) per residue (apply_model.ipynb:160, interfaceome/apply_model.py:76) and its expansion to
 // atoms, bf[c][i] = p[res_of_atom[i]][c] - what encode_bfactor (src/structure.py:208-218) does on the host with one

@@ -186,6 +186,45 @@ class Model:
         if tuple(rs) != (N,):
             raise ValueError(f"residue mask must cover N={N} atoms, got {tuple(rs)}")
 
+    # ------------------------------------------------------------------ list of structures -> one launch (SURVEY 8b)
+    def forward_batch(self, structures):
+        """[z_b] for structures = [(X, ids_topk0, q0, M), ...] exactly as the reference hands them to collate_batch_features
+        (src/dataset.py:91-112; ids_topk0 0-based [N_b, min(64, N_b)] from extract_topology, M the structure's own [N_b, R_b]
+        mask): collated on the device and run as ONE batch. Host arrays (numpy / CPU tensors) in, numpy out."""
+        h = self._ensure()
+        lib = _lib.load()
+        n0, n_out = self.config["em"]["N0"], self.config["dm"]["N2"]
+        nb = len(structures)
+        if nb < 1:
+            return []
+        keep, zs = [], []
+        arr = lambda ct: (ct * nb)()
+        Np, Rp, kp = arr(ctypes.c_int64), arr(ctypes.c_int64), arr(ctypes.c_int32)
+        Xp, Ip, Qp, Ap, Zp = (arr(ctypes.c_void_p) for _ in range(5))
+        kind = None
+        for b, (X, ids, q0, M) in enumerate(structures):
+            roa, R = mask_to_segments(M) if self.validate else (np.asarray(M.detach().cpu().numpy() if _is_torch(M) else M).argmax(1).astype(np.int32), int(M.shape[1]))
+            Xn = np.ascontiguousarray(X.detach().cpu().numpy() if _is_torch(X) else X, dtype=np.float32)
+            idn = ids.detach().cpu().numpy() if _is_torch(ids) else np.asarray(ids)
+            idn = np.ascontiguousarray(idn.astype(np.int32) if idn.dtype != np.int64 else idn)
+            if kind is None:
+                kind = idn.dtype
+            elif idn.dtype != kind:
+                idn = np.ascontiguousarray(idn.astype(kind))
+            qn = np.ascontiguousarray(q0.detach().cpu().numpy() if _is_torch(q0) else q0, dtype=np.float32)
+            roa = np.ascontiguousarray(roa.detach().cpu().numpy() if _is_torch(roa) else roa, dtype=np.int32)
+            N = Xn.shape[0]
+            if idn.ndim != 2 or idn.shape[0] != N:
+                raise ValueError(f"structure {b}: ids_topk must be [N, k] with N={N}")
+            self._check_shapes(N, Xn.shape, qn.shape, roa.shape, n0)
+            z = np.empty((R, n_out), dtype=np.float32)
+            keep.append((Xn, idn, qn, roa))
+            zs.append(z)
+            Np[b], Rp[b], kp[b] = N, R, idn.shape[1]
+            Xp[b], Ip[b], Qp[b], Ap[b], Zp[b] = Xn.ctypes.data, idn.ctypes.data, qn.ctypes.data, roa.ctypes.data, z.ctypes.data
+        _lib.check(lib.pesto_forward_batch(h, nb, Np, Rp, kp, Xp, Ip, _lib.IDS_INT64 if kind == np.int64 else _lib.IDS_INT32, Qp, Ap, Zp, None))
+        return zs
+
     # ------------------------------------------------------------------ trajectory frames (SURVEY 8f row 3)
     def forward_frames(self, X_frames, ids_topk, q0, M, frame_axis=0, frames_per_launch=0):
         """z [F, R, N2] for F coordinate frames of the same atoms with ONE topology: what the reference's MD loop

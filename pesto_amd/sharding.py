@@ -42,7 +42,7 @@ def batches(indices, sizes, max_atoms):
 
 
 def forward_local(forward_fn, structures, indices, max_atoms=32768):
-    """Run ``forward_fn(X, ids_topk, q, M) -> z`` over this rank's structures, collating several per launch.
+    """Run ``forward_fn(X, ids_topk, q, M) -> z`` (or a pesto_amd.Model) over this rank's structures, collating several per launch.
     ``structures[i] = (X, ids_topk0, q, M)`` with the per-structure contract of pesto_amd.topology.
     Returns {index: z_i (numpy [R_i, n_out])}.  A structure whose batch raises is retried alone and skipped on a
     second failure (the reference driver also skips and continues)."""
@@ -51,6 +51,10 @@ def forward_local(forward_fn, structures, indices, max_atoms=32768):
     results = {}
 
     def run(group):
+        if hasattr(forward_fn, "forward_batch"):      # a pesto_amd.Model: collate on the device (pesto_forward_batch)
+            for i, z in zip(group, forward_fn.forward_batch([tuple(structures[i]) for i in group])):
+                results[i] = np.ascontiguousarray(z)
+            return
         X, ids, q, M = collate_batch_features([list(structures[i]) for i in group])
         z = forward_fn(X, ids, q, M)
         z = z.detach().cpu().numpy() if hasattr(z, "detach") else np.asarray(z)

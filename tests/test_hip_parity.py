@@ -389,3 +389,39 @@ def test_apply_model_chain_pdb_to_bfactor_pdb(tmp_path):
     atoms = [l for l in lines if l.startswith(("ATOM", "HETATM"))]
     assert [l[:54] for l in atoms] == [l[:54] for l in want if l.startswith(("ATOM", "HETATM"))]
     assert [float(l[54:60]) for l in atoms] == [float("%.2f" % v) for v in bf[0]]
+
+
+# ---------------------------------------------------------------------------------------------- list of structures
+def _split_batch_fixture(g):
+    """Undo collate_batch_features on the edge_batch2 fixture: per-structure (X, 0-based ids [N_b, min(64, N_b)], q0, M)."""
+    out, a0, r0 = [], 0, 0
+    for n, r in g["sizes"]:
+        n, r = int(n), int(r)
+        kb = min(64, n)
+        ids0 = g["ids_topk"][a0:a0 + n, :kb].astype(np.int64) - a0 - 1
+        roa = g["res_of_atom"][a0:a0 + n] - r0
+        M = np.zeros((n, r), np.float32)
+        M[np.arange(n), roa] = 1.0
+        out.append((g["X"][a0:a0 + n], ids0, onehot(g["q_idx"][a0:a0 + n], 30), M))
+        a0 += n; r0 += r
+    return out
+
+
+def test_forward_batch_collates_on_device_like_the_reference():
+    from pesto_amd._lib import PestoError
+    g = golden("edge_batch2")                      # reference collate_batch_features + forward on 300 + 40 atoms
+    m = _model("i_v4_0")
+    structs = _split_batch_fixture(g)
+    zs = m.forward_batch(structs)
+    assert [z.shape[0] for z in zs] == [int(r) for _, r in g["sizes"]]
+    z = np.concatenate(zs, 0)
+    assert np.abs(z - g["z"]).max() < 1e-4
+    zc = m.forward_segments(g["X"], g["ids_topk"], onehot(g["q_idx"], 30), g["res_of_atom"], g["z"].shape[0])
+    assert np.array_equal(z, zc)                   # same kernels on the same collated arrays
+    z32 = m.forward_batch([(X, ids.astype(np.int32), q, M) for X, ids, q, M in structs])
+    assert np.array_equal(np.concatenate(z32, 0), z)
+    bad = [list(s) for s in structs]
+    bad[1][1] = bad[1][1].copy(); bad[1][1][0, 0] = 40      # index outside its own structure (would alias the next one)
+    with pytest.raises(PestoError):
+        m.forward_batch([tuple(s) for s in bad])
+    assert np.array_equal(np.concatenate(m.forward_batch(structs), 0), z)
