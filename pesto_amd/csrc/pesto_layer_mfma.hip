@@ -31,28 +31,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
-// fp32 -> (hi, lo) f16 pair with x = hi + lo to ~2^-21 relative: hi = rtz16(x), lo = rn16(x - hi) (the residual is
+// fp32 -> (hi, lo) f16 pair with x = hi + lo to ~2^-21 relative: hi = rtz16(x), lo = rtz16(x - hi) (the residual is
 // exact in fp32). Two 16-feature blocks (4 + 4 values of this lane) form the 8 k-values one lane feeds to
 // v_mfma_f32_16x16x32_f16. Three MFMAs (hi*hi, lo*hi, hi*lo) then reproduce the fp32 product to ~2^-21.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// lo pair = f16(v0 - hi.lo), f16(v1 - hi.hi): one mixed-precision fma each (fp32 arithmetic on the f16 operand, f16 result,
-// round to nearest) instead of convert + subtract + convert. The compiler folds fma(h, -1, x) back into a subtract, hence asm.
-__device__ __forceinline__ unsigned resid_pack(unsigned hpair, float v0, float v1) {
-    unsigned lo;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hpair), "v"(v0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hpair), "v"(v1));
-    return lo;
-}
+// NOTE: the residual could be one v_fma_mixlo/mixhi_f16 per element (f16(x - hi) in a single mixed-precision fma), but the
+// compiler only emits those from inline asm, and inline asm is invisible to the MFMA hazard recogniser: a register it
+// overwrites may still be read as SrcC by an in-flight MFMA (seen as rare, timing-dependent corruption in a node-kernel
+// variant). Plain convert / subtract / convert costs 3 more VALU per pair and is hazard-checked.
 __device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
     const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    u32x4 h, l;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * j], v[2 * j + 1]));
-        l[j] = resid_pack(h[j], v[2 * j], v[2 * j + 1]);
+    for (int j = 0; j < 8; j += 2) {
+        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v[j], v[j + 1]);
+        const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(v[j] - (float)h[0], v[j + 1] - (float)h[1]);
+        hi[j] = (_Float16)h[0]; hi[j + 1] = (_Float16)h[1];
+        lo[j] = (_Float16)l[0]; lo[j + 1] = (_Float16)l[1];
     }
-    hi = __builtin_bit_cast(f16x8, h);
-    lo = __builtin_bit_cast(f16x8, l);
 }
 __device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast<const f16x8*>(p); }
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
