@@ -278,186 +278,189 @@ __device__ __forceinline__ void mfma16_multi(const float* __restrict__ wf, int m
     for (int m = 0; m < NM; ++m) acc[m] = MFMA16(wl[m], xh, acc[m]);
 }
 
-// node kernel on the f16-split MFMA path (same contract as k_node; 321 f16 MFMAs instead of 856 fp32 MFMAs per 16 atoms).
-// Weight fragments are staged through LDS in three phases (finish: 24 KB, [U|A]: 64 KB, [G|C] + nqm: 46 KB) by all four
-// waves of the workgroup: a wave alone would wait an L2 round trip (~800 cycles) for every 12-MFMA group.
-constexpr int NODE_LDS_FLOATS = 16384;
-__device__ __forceinline__ void node_fill(float* lds, const float* __restrict__ src, int n_floats) {
-    __syncthreads();                                  // previous phase's readers are done
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-    f32x4* d4 = reinterpret_cast<f32x4*>(lds);
-    for (int k = threadIdx.x; k < n_floats / 4; k += 256) d4[k] = s4[k];
-    __syncthreads();
-}
-
+// node kernel on the f16-split MFMA path (same contract as k_node; 249 f16 MFMAs per 16 atoms on the hybrid path, 321 with
+// full neighbour records, instead of 856 fp32 MFMAs).
+// The kernel is LATENCY-bound, not throughput-bound: 24k atoms are only 1,500 wave tiles for 1,024 SIMDs, so its duration is
+// the length of one wave's dependent chain. All weight fragments of both halves (finish 24 KB, [U|A] 64 KB, [G|C] 16/32 KB,
+// nqm 14 KB) are therefore staged into LDS by ONE fill per workgroup (eight waves, one workgroup per CU) that overlaps the
+// state / Z loads - three sequential fill-barrier-compute phases per workgroup cost 27 us per launch, 15 % of a forward.
 // HY (hybrid edge kernel): the neighbour record shrinks to A_j[128] in natural feature order (REC_A floats per atom); the
 // C_j[c] = W[:,161:193] p_j[c] pieces are no longer materialised - the edge kernel applies that block per edge on the matrix
 // cores from the gathered p_j (4x less gather traffic than the 2 KB record, which was the edge kernel's bottleneck).
+constexpr int NODE_WAVES = 8;
+constexpr int NL_FIN = 0, NL_UA = 6144, NL_GC = NL_UA + 16384;
+template <bool HY> constexpr int nl_nq() { return NL_GC + (HY ? 4096 : 8192); }
+template <bool HY> constexpr int node_lds_floats() { return nl_nq<HY>() + 3584; }
+
+// Four waves share one 16-atom tile (role = wave & 3) so that the dependent chain a wave walks is ~70 MFMAs, not 249:
+//   finish: role 0 -> qpm (q update), roles 1..3 -> ppm for xyz component role - 1; the updated tile state is exchanged through
+//           LDS (8 KB per tile) behind one workgroup barrier;
+//   prep  : role r -> [U|A] output blocks 4r..4r+3 and [G|C] blocks 2r, 2r+1 (and 8+2r, 9+2r without HY); role 3 also nqm.
+// Workgroups are persistent (eight waves = two tiles per iteration, weights resident in LDS).
 template <bool HY>
-__global__ __launch_bounds__(256, 2) void k_node16(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
+__global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
                                                 int N1, float* __restrict__ q_state, float* __restrict__ p_state,
                                                 const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen) {
     const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
-    const int n_tiles = (N1 + 15) >> 4, chunk = (n_tiles + 7) >> 3;
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    __shared__ __attribute__((aligned(16))) float wl_[NODE_LDS_FLOATS];
-    const int tile_raw = xcd * chunk + jb * 4 + (threadIdx.x >> 6);
-    const bool live = tile_raw < min(n_tiles, (xcd + 1) * chunk);     // dead waves still help filling LDS
-    const int tile = live ? tile_raw : 0;
-    const int i_raw = tile * 16 + e;
-    const bool valid = live && i_raw < N1;
-    const int i = (i_raw < N1) ? i_raw : N1 - 1;
-
-    f32x4 q[2], p[3][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        q[m] = ld4(q_state + (size_t)i * S + 16 * m + 4 * g);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) p[c][m] = ld4(p_state + (size_t)i * 96 + c * 32 + 16 * m + 4 * g);
-    }
-    f16x8 xh, xl;
-    if (do_finish) {
-        node_fill(wl_, W + wf_.h_q0, 6144);            // [q0 | q1 | q2 | pp] f16 fragment tables, contiguous in the image
-        const float* Lq0 = wl_, *Lq1 = wl_ + 2048, *Lq2 = wl_ + 3072, *Lpp = wl_ + 4096;
-        const float* zr = Z + (size_t)i * REC_Z;
-        f32x4 h[2], t[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) h[m] = ld4(W + wf_.n_bq0 + 16 * m + 4 * g);
-#pragma unroll
-        for (int kgp = 0; kgp < 2; ++kgp) {
-            split8(ld4(zr + 32 * kgp + 4 * g), ld4(zr + 32 * kgp + 16 + 4 * g), xh, xl);
-            mfma16_multi<2>(Lq0, 0, 2, kgp, lane, xh, xl, h);
+    // wave-uniform by construction; readfirstlane makes it uniform for the compiler too (scalar branches around the MFMA blocks)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), role = wave & 3, slot = wave >> 2;
+    __shared__ __attribute__((aligned(16))) float wl_[node_lds_floats<HY>()];
+    __shared__ __attribute__((aligned(16))) float xch[2][8][256];     // [tile slot][q0 q1 p00 p01 p10 p11 p20 p21][lane][4]
+    {   // one fill: [q0 | q1 | q2 | pp] (contiguous in the image), [U|A], [G|C] (G half only when HY), [n0 | n1 | n2]
+        auto copy = [&](int dst, const float* src, int n_floats) {
+            const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+            f32x4* d4 = reinterpret_cast<f32x4*>(wl_ + dst);
+            for (int k = threadIdx.x; k < n_floats / 4; k += NODE_WAVES * 64) d4[k] = s4[k];
+        };
+        if (do_finish) copy(NL_FIN, W + wf_.h_q0, 6144);
+        if (do_prep) {
+            copy(NL_UA, W + wp_.h_ua, 16384);
+            copy(NL_GC, W + wp_.h_gc, HY ? 4096 : 8192);
+            copy(nl_nq<HY>(), W + wp_.h_n0, 3584);
         }
+    }
+    // XCD-aware partition of tile PAIRS (same atom ranges per XCD as the edge kernel's work items)
+    const int n_tiles = (N1 + 15) >> 4, n_pairs = (n_tiles + 1) >> 1, chunk = (n_pairs + 7) >> 3;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    const int p_end = min(n_pairs, (xcd + 1) * chunk);
+    bool first = true;
+    for (int pair = xcd * chunk + jb; pair < p_end; pair += nbx) {
+        const int tile = 2 * pair + slot;
+        const bool live = tile < n_tiles;
+        const int i_raw = (live ? tile : 0) * 16 + e;
+        const bool valid = live && i_raw < N1;
+        const int i = (i_raw < N1) ? i_raw : N1 - 1;
+        float* xs = &xch[slot][0][0];
+
+        // this role's slice of the state: role 0 -> q, role c + 1 -> p[c]
+        const float* src = role == 0 ? q_state + (size_t)i * S : p_state + (size_t)i * 96 + (role - 1) * 32;
+        f32x4 st[2] = {ld4(src + 4 * g), ld4(src + 16 + 4 * g)};
+        f16x8 xh, xl;
+        if (first) { __syncthreads(); first = false; }      // weights are in LDS
+        if (do_finish) {
+            const float* Lq0 = wl_ + NL_FIN, *Lq1 = Lq0 + 2048, *Lq2 = Lq0 + 3072, *Lpp = Lq0 + 4096;
+            const float* zr = Z + (size_t)i * REC_Z;
+            if (role == 0) {   // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147, :151)
+                f32x4 h[2], t[2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) { h[m] = elu4(h[m]); t[m] = ld4(W + wf_.n_bq1 + 16 * m + 4 * g); }
-        split8(h[0], h[1], xh, xl);
-        mfma16_multi<2>(Lq1, 0, 1, 0, lane, xh, xl, t);
+                for (int m = 0; m < 2; ++m) h[m] = ld4(W + wf_.n_bq0 + 16 * m + 4 * g);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) { t[m] = elu4(t[m]); h[m] = ld4(W + wf_.n_bq2 + 16 * m + 4 * g); }
-        split8(t[0], t[1], xh, xl);
-        mfma16_multi<2>(Lq2, 0, 1, 0, lane, xh, xl, h);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) q[m] += h[m];
-        {   // ppm: the three xyz components share each weight fragment (6 independent accumulators)
-            f32x4 a[3][2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { a[c][0] = f32x4{0, 0, 0, 0}; a[c][1] = f32x4{0, 0, 0, 0}; }
-#pragma unroll
-            for (int kgp = 0; kgp < 2; ++kgp) {
-                f16x8 wh[2], wl[2], zh[3], zl[3];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const float* fr = Lpp + (size_t)((m * 2 + kgp) * 2) * 256 + lane * 4;
-                    wh[m] = ld8h(fr); wl[m] = ld8h(fr + 256);
+                for (int kgp = 0; kgp < 2; ++kgp) {
+                    split8(ld4(zr + 32 * kgp + 4 * g), ld4(zr + 32 * kgp + 16 + 4 * g), xh, xl);
+                    mfma16_multi<2>(Lq0, 0, 2, kgp, lane, xh, xl, h);
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    split8(ld4(zr + 64 + c * 64 + 32 * kgp + 4 * g), ld4(zr + 64 + c * 64 + 32 * kgp + 16 + 4 * g), zh[c], zl[c]);
+                for (int m = 0; m < 2; ++m) { h[m] = elu4(h[m]); t[m] = ld4(W + wf_.n_bq1 + 16 * m + 4 * g); }
+                split8(h[0], h[1], xh, xl);
+                mfma16_multi<2>(Lq1, 0, 1, 0, lane, xh, xl, t);
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                for (int m = 0; m < 2; ++m) { t[m] = elu4(t[m]); h[m] = ld4(W + wf_.n_bq2 + 16 * m + 4 * g); }
+                split8(t[0], t[1], xh, xl);
+                mfma16_multi<2>(Lq2, 0, 1, 0, lane, xh, xl, h);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) a[c][m] = MFMA16(wh[m], zh[c], a[c][m]);
+                for (int m = 0; m < 2; ++m) st[m] += h[m];
+            } else {           // ppm: 64 -> 32, no bias, xyz component role - 1             (:148, :152)
+                f32x4 a[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+                const float* zc = zr + 64 + (role - 1) * 64;
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) a[c][m] = MFMA16(wh[m], zl[c], a[c][m]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) a[c][m] = MFMA16(wl[m], zh[c], a[c][m]);
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { p[c][0] += a[c][0]; p[c][1] += a[c][1]; }
-        }
-        if (i == 0) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) { q[m] = f32x4{0, 0, 0, 0}; p[0][m] = q[m]; p[1][m] = q[m]; p[2][m] = q[m]; }
-        }
-        if (valid) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                st4(q_state + (size_t)i * S + 16 * m + 4 * g, q[m]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) st4(p_state + (size_t)i * 96 + c * 32 + 16 * m + 4 * g, p[c][m]);
-            }
-        }
-    }
-    if (!do_prep) return;
-
-    node_fill(wl_, W + wp_.h_ua, 16384);               // [U|A] fragments (64 KB)
-    f32x4 pn[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            pn[m][r] = sqrtf(p[0][m][r] * p[0][m][r] + p[1][m][r] * p[1][m][r] + p[2][m][r] * p[2][m][r]);
-    f16x8 xnh[2], xnl[2], ph[3], pl[3];
-    split8(q[0], q[1], xnh[0], xnl[0]);
-    split8(pn[0], pn[1], xnh[1], xnl[1]);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) split8(p[c][0], p[c][1], ph[c], pl[c]);
-
-    float* cen = rec_cen + (size_t)i * REC_CEN;
-    float* nb = rec_nb + (size_t)i * (HY ? REC_A : REC_NB);
-#pragma unroll 1
-    for (int ob = 0; ob < 16; ob += 4) {
-        f32x4 a[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = ob < 8 ? ld4(W + wp_.n_b1 + 16 * (ob + j) + 4 * g) : f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<4>(wl_, ob, 2, kgp, lane, xnh[kgp], xnl[kgp], a);
-        if (valid) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);
-                else if (HY) st4(nb + (ob + j - 8) * 16 + 4 * g, a[j]);           // A_j[16 fb + 4g + r]
-                else st4(nb + ((ob + j - 8) * 4 + g) * 16, a[j]);
-            }
-        }
-    }
-    node_fill(wl_, W + wp_.h_gc, HY ? 4096 : 8192);    // [G|C] fragments (32 KB; the G half only on the hybrid path) ...
-    for (int k = threadIdx.x; k < 3584 / 4; k += 256)  // ... followed by the nqm tables [n0 | n1 | n2] (14 KB)
-        reinterpret_cast<f32x4*>(wl_ + 8192)[k] = reinterpret_cast<const f32x4*>(W + wp_.h_n0)[k];
-    __syncthreads();
-#pragma unroll 1
-    for (int ob = 0; ob < (HY ? 8 : 16); ob += 2) {
-        f32x4 a[2][3];
-        f16x8 wh[2], wl[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float* fr = wl_ + (size_t)((ob + j) * 2) * 256 + lane * 4;
-            wh[j] = ld8h(fr); wl[j] = ld8h(fr + 256);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) a[j][c] = f32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wh[0], ph[c], a[0][c]); a[1][c] = MFMA16(wh[1], ph[c], a[1][c]); }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wh[0], pl[c], a[0][c]); a[1][c] = MFMA16(wh[1], pl[c], a[1][c]); }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wl[0], ph[c], a[0][c]); a[1][c] = MFMA16(wl[1], ph[c], a[1][c]); }
-        if (valid) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (ob < 8) st4(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
-                    else st4(nb + ((ob + j - 8) * 4 + g) * 16 + (1 + c) * 4, a[j][c]);
+                for (int kgp = 0; kgp < 2; ++kgp) {
+                    split8(ld4(zc + 32 * kgp + 4 * g), ld4(zc + 32 * kgp + 16 + 4 * g), xh, xl);
+                    mfma16_multi<2>(Lpp, 0, 2, kgp, lane, xh, xl, a);
                 }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) st[m] += a[m];
+            }
+            if (i == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
+            if (valid) {
+                float* dst = role == 0 ? q_state + (size_t)i * S : p_state + (size_t)i * 96 + (role - 1) * 32;
+                st4(dst + 4 * g, st[0]); st4(dst + 16 + 4 * g, st[1]);
+            }
         }
-    }
-    {
-        f32x4 h[2], t[2];
+        if (!do_prep) continue;
+        // exchange the tile state between the four roles
+        st4(xs + (2 * role) * 256 + lane * 4, st[0]);
+        st4(xs + (2 * role + 1) * 256 + lane * 4, st[1]);
+        __syncthreads();
+        f32x4 q[2], p[3][2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) { h[m] = ld4(W + wp_.n_bn0 + 16 * m + 4 * g); t[m] = ld4(W + wp_.n_bn1 + 16 * m + 4 * g); }
+        for (int m = 0; m < 2; ++m) {
+            q[m] = ld4(xs + m * 256 + lane * 4);
 #pragma unroll
-        for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<2>(wl_ + 8192, 0, 2, kgp, lane, xnh[kgp], xnl[kgp], h);
-        split8(elu4(h[0]), elu4(h[1]), xh, xl);
-        mfma16_multi<2>(wl_ + 8192 + 2048, 0, 1, 0, lane, xh, xl, t);
-        f32x4 qq[1] = {ld4(W + wp_.n_bn2 + 4 * g)};
-        split8(elu4(t[0]), elu4(t[1]), xh, xl);
-        mfma16_multi<1>(wl_ + 8192 + 3072, 0, 1, 0, lane, xh, xl, qq);
-        if (valid) st4(cen + 512 + 4 * g, qq[0]);
+            for (int c = 0; c < 3; ++c) p[c][m] = ld4(xs + (2 + 2 * c + m) * 256 + lane * 4);
+        }
+        __syncthreads();                                     // the next iteration overwrites the exchange buffer
+
+        const float* Lua = wl_ + NL_UA, *Lgc = wl_ + NL_GC, *Lnq = wl_ + nl_nq<HY>();
+        f32x4 pn[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                pn[m][r] = sqrtf(p[0][m][r] * p[0][m][r] + p[1][m][r] * p[1][m][r] + p[2][m][r] * p[2][m][r]);
+        f16x8 xnh[2], xnl[2], ph[3], pl[3];
+        split8(q[0], q[1], xnh[0], xnl[0]);
+        split8(pn[0], pn[1], xnh[1], xnl[1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) split8(p[c][0], p[c][1], ph[c], pl[c]);
+
+        float* cen = rec_cen + (size_t)i * REC_CEN;
+        float* nb = rec_nb + (size_t)i * (HY ? REC_A : REC_NB);
+        {   // [U | A] output blocks 4 role .. 4 role + 3 (U = blocks 0..7 carries b1, A = blocks 8..15)
+            const int ob = 4 * role;
+            f32x4 a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = ob < 8 ? ld4(W + wp_.n_b1 + 16 * (ob + j) + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<4>(Lua, ob, 2, kgp, lane, xnh[kgp], xnl[kgp], a);
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);
+                    else if (HY) st4(nb + (ob + j - 8) * 16 + 4 * g, a[j]);           // A_j[16 fb + 4g + r]
+                    else st4(nb + ((ob + j - 8) * 4 + g) * 16, a[j]);
+                }
+            }
+        }
+#pragma unroll 1
+        for (int ob = 2 * role; ob < (HY ? 8 : 16); ob += 8) {   // [G | C] blocks 2 role, 2 role + 1 (and + 8 without HY)
+            f32x4 a[2][3];
+            f16x8 wh[2], wl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float* fr = Lgc + (size_t)((ob + j) * 2) * 256 + lane * 4;
+                wh[j] = ld8h(fr); wl[j] = ld8h(fr + 256);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a[j][c] = f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wh[0], ph[c], a[0][c]); a[1][c] = MFMA16(wh[1], ph[c], a[1][c]); }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wh[0], pl[c], a[0][c]); a[1][c] = MFMA16(wh[1], pl[c], a[1][c]); }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wl[0], ph[c], a[0][c]); a[1][c] = MFMA16(wl[1], ph[c], a[1][c]); }
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (ob < 8) st4(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
+                        else st4(nb + ((ob + j - 8) * 4 + g) * 16 + (1 + c) * 4, a[j][c]);
+                    }
+            }
+        }
+        if (role == 3) {   // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12                        (:119)
+            f32x4 h[2], t[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { h[m] = ld4(W + wp_.n_bn0 + 16 * m + 4 * g); t[m] = ld4(W + wp_.n_bn1 + 16 * m + 4 * g); }
+#pragma unroll
+            for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<2>(Lnq, 0, 2, kgp, lane, xnh[kgp], xnl[kgp], h);
+            split8(elu4(h[0]), elu4(h[1]), xh, xl);
+            mfma16_multi<2>(Lnq + 2048, 0, 1, 0, lane, xh, xl, t);
+            f32x4 qq[1] = {ld4(W + wp_.n_bn2 + 4 * g)};
+            split8(elu4(t[0]), elu4(t[1]), xh, xl);
+            mfma16_multi<1>(Lnq + 3072, 0, 1, 0, lane, xh, xl, qq);
+            if (valid) st4(cen + 512 + 4 * g, qq[0]);
+        }
     }
 }
 
@@ -1171,9 +1174,20 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
                  const float* Z, float* rec_nb, float* rec_cen, int variant) {
     const int tiles = (N1 + 15) / 16, chunk = (tiles + 7) / 8;
     const LayerW dummy{};
-    auto kern = variant == 1 ? k_node : variant == 0 ? k_node16<true> : k_node16<false>;
-    hipLaunchKernelGGL(kern, dim3((chunk + 3) / 4 * 8), dim3(256), 0, st, W, finish ? *finish : dummy, prep ? *prep : dummy,
-                       finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
+    const LayerW& wf = finish ? *finish : dummy;
+    const LayerW& wp = prep ? *prep : dummy;
+    if (variant == 1) {
+        hipLaunchKernelGGL(k_node, dim3((chunk + 3) / 4 * 8), dim3(256), 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z,
+                           rec_nb, rec_cen);
+        return;
+    }
+    // eight waves = two tiles per iteration; persistent workgroups, at most one per CU (32 per XCD)
+    const int pair_chunk = ((tiles + 1) / 2 + 7) / 8;
+    const dim3 grid((pair_chunk < 32 ? pair_chunk : 32) * 8), block(NODE_WAVES * 64);
+    if (variant == 0)
+        hipLaunchKernelGGL(k_node16<true>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
+    else
+        hipLaunchKernelGGL(k_node16<false>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
 }
 
 template <int WPB, bool PF, bool F16, bool HY = false>
