@@ -425,3 +425,23 @@ def test_forward_batch_collates_on_device_like_the_reference():
     with pytest.raises(PestoError):
         m.forward_batch([tuple(s) for s in bad])
     assert np.array_equal(np.concatenate(m.forward_batch(structs), 0), z)
+
+
+def test_sharding_forward_local_uses_device_collate():
+    """pesto_amd.sharding.forward_local with a Model goes through pesto_forward_batch; results = one structure at a time,
+    except that a collated batch shares one max(D) (only matters below 1e-2 A: none here) - compare within the parity bound."""
+    from pesto_amd.sharding import forward_local
+    from pesto_amd.topology import extract_topology, synthetic_structure
+    m = _model("i_v4_0")
+    structs = []
+    for i, n in enumerate((300, 180, 96)):
+        X, _, q, M = synthetic_structure(n, 40 + i, n0=30)
+        structs.append((X, extract_topology(X, 64), q, M))
+    res = forward_local(m, structs, [0, 1, 2], max_atoms=500)      # -> launches of (300), (180 + 96)
+    for i, (X, ids, q, M) in enumerate(structs):
+        one = m.forward_batch([(X, ids, q, M)])[0]
+        assert res[i].shape == one.shape and np.abs(res[i] - one).max() < 1e-4
+    zo = _oracle("i_v4_0")
+    roa = structs[0][3].argmax(1).astype(np.int32)
+    ref = zo.forward_segments(structs[0][0], (structs[0][1] + 1).astype(np.int32), structs[0][2], roa, structs[0][3].shape[1])
+    assert np.abs(res[0] - ref).max() < 1e-4
