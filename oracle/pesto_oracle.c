@@ -294,7 +294,7 @@ int oracle_layer(const struct oracle_model* m, int layer, int64_t N1, int k, con
 
             float Zq[NH * S], Zp[3][NH * S];
             for (int h = 0; h < NH; ++h) {
-                float Mq[64], Mp[3 * 64];
+                float Mq[64] = {0}, Mp[3 * 64] = {0};
                 for (int c = 0; c < n; ++c) {                          /* :139 */
                     float a = 0.0f;
                     for (int kk = 0; kk < NK; ++kk) a += Q[h * NK + kk] * Kq[c * NK + kk];
