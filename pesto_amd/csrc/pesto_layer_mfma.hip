@@ -50,6 +50,11 @@ __device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
     }
 }
 __device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast<const f16x8*>(p); }
+#ifdef PESTO_ABL_NOWL   // ablation: the low weight fragments are not read from LDS (results wrong): -1/3 of the LDS weight traffic
+#define PESTO_WL(fr) ld8h(fr) 
+#else
+#define PESTO_WL(fr) ld8h((fr) + 256)
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 #ifdef PESTO_ABL_NOMFMA   // ablation: the MFMA becomes one VALU op keeping the data dependence
 #define MFMA(a, b, c) ((c) + (a) * (b))
@@ -268,7 +273,7 @@ __device__ __forceinline__ void mfma16_multi(const float* __restrict__ wf, int m
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         const float* fr = wf + (size_t)(((m0 + m) * nkg + kgp) * 2) * 256 + lane * 4;
-        wh[m] = ld8h(fr); wl[m] = ld8h(fr + 256);
+        wh[m] = ld8h(fr); wl[m] = PESTO_WL(fr);
     }
 #pragma unroll
     for (int m = 0; m < NM; ++m) acc[m] = MFMA16(wh[m], xh, acc[m]);
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float* fr = Lgc + (size_t)((ob + j) * 2) * 256 + lane * 4;
-                wh[j] = ld8h(fr); wl[j] = ld8h(fr + 256);
+                wh[j] = ld8h(fr); wl[j] = PESTO_WL(fr);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) a[j][c] = f32x4{0, 0, 0, 0};
             }
@@ -642,7 +647,7 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) {
             const float* fr = w1p + (size_t)((fb0 + m0 + ml) * 2) * 256 + lane * 4;
-            wh[ml] = ld8h(fr); wl[ml] = ld8h(fr + 256);
+            wh[ml] = ld8h(fr); wl[ml] = PESTO_WL(fr);
         }
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) o.acc[m0 + ml] = MFMA16(wh[ml], o.fh, o.acc[m0 + ml]);
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {      // a = net * 2 + ml; fragment order [net][ml][hi|lo]
                         const float* fr = w2f + (size_t)(a * 2) * 256 + lane * 4;
-                        wh[a] = ld8h(fr); wl[a] = ld8h(fr + 256);
+                        wh[a] = ld8h(fr); wl[a] = PESTO_WL(fr);
                     }
 #pragma unroll
                     for (int a = 0; a < 4; ++a) acc2[a] = MFMA16(wh[a], xh[a >> 1], acc2[a]);
@@ -751,7 +756,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                     for (int kgp = 0; kgp < 2; ++kgp) {
                         const float* fr = w3k + (size_t)(kgp * 2) * 256 + lane * 4;
-                        kh[kgp] = ld8h(fr); kl[kgp] = ld8h(fr + 256);
+                        kh[kgp] = ld8h(fr); kl[kgp] = PESTO_WL(fr);
                     }
                     kacc = MFMA16(kh[0], xh[0], kacc); kacb = MFMA16(kh[1], xh[1], kacb);
                     kacc = MFMA16(kh[0], xl[0], kacc); kacb = MFMA16(kh[1], xl[1], kacb);
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                         for (int ml = 0; ml < G; ++ml) {
                             const float* fr = w2f + 8 * 256 + (size_t)(((m0 + ml) * 2 + kgp) * 2) * 256 + lane * 4;
-                            wh[ml] = ld8h(fr); wl[ml] = ld8h(fr + 256);
+                            wh[ml] = ld8h(fr); wl[ml] = PESTO_WL(fr);
                         }
 #pragma unroll
                         for (int ml = 0; ml < G; ++ml) acc2[m0 + ml] = MFMA16(wh[ml], xh, acc2[m0 + ml]);
@@ -1034,7 +1039,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                         for (int fo = 0; fo < G; ++fo) {
                             const float* fr = w3v + (size_t)(((f0 + fo) * 2 + kgp) * 2) * 256 + lane * 4;
-                            bh[fo] = ld8h(fr); bl[fo] = ld8h(fr + 256);
+                            bh[fo] = ld8h(fr); bl[fo] = PESTO_WL(fr);
                         }
 #pragma unroll
                         for (int fo = 0; fo < G; ++fo) v[f0 + fo] = MFMA16(ah, bh[fo], v[f0 + fo]);
