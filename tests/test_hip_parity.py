@@ -468,3 +468,15 @@ def test_tiny_structures_vs_oracle(n, impl):
         assert np.abs(z_h - z_o).max() < 1e-4
     else:                                   # N = 1: D = 0 everywhere -> 0/0 in the reference too; both sides must agree on where
         assert np.array_equal(np.isfinite(z_h), np.isfinite(z_o))
+
+
+@pytest.mark.parametrize("fixture", ["fwd_i_v4_0_2CUA", "fwd_i_v4_0_2AYO"])
+def test_knn_on_real_chains_matches_reference_topology(fixture):
+    """GPU k-NN on real protein coordinates (2CUA: 955 atoms, 2AYO: 2,810 atoms) against the ids the reference's
+    extract_topology + collate_batch_features produced for the whole-forward fixtures."""
+    g = golden(fixture)
+    m = _model("i_v4_0")
+    ids = m.knn_collate(g["X"], [g["X"].shape[0]])
+    _check_same_neighbours(ids, g["ids_topk"].astype(np.int64), g["X"])
+    z = m.forward_segments(g["X"], ids, onehot(g["q_idx"], 30), g["res_of_atom"], g["z"].shape[0])
+    assert np.abs(z - g["z"]).max() < 1e-4
