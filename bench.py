@@ -173,13 +173,14 @@ def main():
     # ---- roofline leg: HIP events around the state-update launches, on the stream they run on
     model.set_timing(True)
     lay_ms = []
-    for _ in range(max(3, min(args.steps, 10))):
+    for _ in range(max(5, min(args.steps, 20))):
         step()
         torch.cuda.synchronize()
         lay_ms.append(model.get_timing())
     model.set_timing(False)
     layers_ms = float(np.median([t["layers_ms"] for t in lay_ms]))
-    fwd_ms = float(np.median([t["total_ms"] for t in lay_ms]))
+    fwd_all = np.array([t["total_ms"] for t in lay_ms])
+    fwd_ms = float(np.median(fwd_all))
     n_launch = lay_ms[0]["n_layer_launches"]
     n1 = n_atoms_total + 1
     flops = sum(layer_flops_per_atom(l["nn"]) for l in config["sum"]) * n1
@@ -235,6 +236,7 @@ def main():
                          "frac": achieved_tf / PEAK_F32_TFLOPS, "traffic": traffic,
                          "flops_per_forward": flops, "launches": n_launch, "avg_launch_ms": layers_ms / n_launch,
                          "layers_ms": layers_ms, "forward_ms": fwd_ms,
+                         "forward_ms_p10_p90": [float(np.percentile(fwd_all, 10)), float(np.percentile(fwd_all, 90))],
                          "executed_mfma_tflops": executed_mfma_flops(config, n1) / (layers_ms * 1e-3) / 1e12,
                          "note": "achieved = reference-formulation FLOPs (SURVEY 8d) of all layer launches of one forward / their "
                                  "HIP-event time; peak = dense fp32 MFMA. The kernels execute ~2.5x fewer FLOPs (most of the first edge "
