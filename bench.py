@@ -246,7 +246,7 @@ def main():
                              "frac": achieved_gbs / PEAK_HBM_GBS, "bytes_per_forward": gbytes,
                              "note": "gather-counted algorithmic bytes (SURVEY 8d definition A) / layer-kernel time"},
         }
-        if args.cpu_budget > 0:
+        if args.cpu_budget > 0 and world == 1:      # the CPU baseline is a 1-GPU-run side measurement (rank 0, N = 1 only)
             out["cpu_baseline"] = cpu_baseline(config, sd, args.atoms, args.cpu_budget)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
