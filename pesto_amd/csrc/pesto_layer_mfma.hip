@@ -679,13 +679,16 @@ __device__ __forceinline__ void l1_tile_lean(int fb0, int lane, int g, const Til
     }
 }
 
-template <int NN, int WPB, bool PF, bool F16, bool HY = false>
+template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
                                                  const float* __restrict__ p_state, float* __restrict__ Z) {
-    constexpr int A = 64 / NN;                 // centres per wave work item (64 edge rows)
+    // TI = 16-edge tiles per wave work item: 4 (64 edge rows) for full launches; small launches (one structure) use finer
+    // items - 1 tile for nn = 8 / 16, 2 for nn = 32 - so that the launch is spread over more waves and CUs (latency)
+    constexpr int A = 16 * TI / NN;            // whole centres per work item
     constexpr int TPC = NN >= 16 ? NN / 16 : 1;   // tiles per centre
+    static_assert(TI >= TPC && TI % TPC == 0 && A >= 1 && (!PF || TI == 4), "a work item holds whole centres");
     static_assert(!HY || (F16 && !PF), "the hybrid first layer exists on the lean f16-split path only");
     __shared__ EdgeSmem<WPB, HY> sm;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         PHASE_INIT();
         {   // rows of this work item: lane = row
             const int a = lane / NN, c = lane % NN, i = c0 + a;
-            const bool valid = i < N1;
+            const bool valid = i < N1 && lane < 16 * TI;
             const size_t src = (size_t)min(i, N1 - 1) * KMAX + c;           // unconditional loads, select afterwards
             const int nbv = ids_s[src];
             const float4 gg = geo[src];
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                 for (int fb = 0; fb < 4; ++fb) ops[0][fb] = l1_fetch<NN>(fb, lane, g, tc[0].cenA, tc[0].cenB, tc[0].recj);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < TI; ++t) {
                     const TileCtx& tcc = tc[t & 1];
                     f32x4 h1[4];
 #pragma unroll
@@ -832,10 +835,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     TileCtx tcc = tile_ctx<NN, HY>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
                     L1Raw raw = l1_issue<NN>(0, 0, lane, tcc, ws, p_state);
 #pragma unroll 1
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < TI; ++t) {
                         L1Head hd = l1_head<NN>(raw, t, lane, tcc, ws);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (t < 3) {
+                        if (t < TI - 1) {
                             tcc = tile_ctx<NN, HY>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
                             raw = l1_issue<NN>(0, t + 1, lane, tcc, ws, p_state);
                         }
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     }
                 } else {
 #pragma unroll 1
-                    for (int t = 0; t < 4; ++t) {   // register-lean: rolled loop, operands fetched block by block
+                    for (int t = 0; t < TI; ++t) {   // register-lean: rolled loop, operands fetched block by block
                         const TileCtx tcc = tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
                         f32x4 h1[4];
                         l1_tile_lean<NN>(0, lane, g, tcc, sm.w + EL_WD, h1);
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         }
         float lg[4][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { lg[t][0] = ws.wts[g][16 * t + e]; lg[t][1] = ws.wts[4 + g][16 * t + e]; }
+        for (int t = 0; t < TI; ++t) { lg[t][0] = ws.wts[g][16 * t + e]; lg[t][1] = ws.wts[4 + g][16 * t + e]; }
         PHASE_MARK(1);
         // ------------------------------------------------------------------ softmax per centre  (:139-140)
         // scalar: over the NN rows of part 0; vector: over the 3*NN slots of parts 1..3 together
@@ -865,11 +868,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         for (int h = 0; h < 2; ++h) {
             float mx[4], ex[4], sr[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) mx[t] = lg[t][h];
+            for (int t = 0; t < TI; ++t) mx[t] = lg[t][h];
             if (TPC == 4) { const float m = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])); mx[0] = mx[1] = mx[2] = mx[3] = m; }
-            if (TPC == 2) { const float m0 = fmaxf(mx[0], mx[1]), m1 = fmaxf(mx[2], mx[3]); mx[0] = mx[1] = m0; mx[2] = mx[3] = m1; }
+            if (TPC == 2) {
+                const float m0 = fmaxf(mx[0], mx[1]); mx[0] = mx[1] = m0;
+                if (TI == 4) { const float m1 = fmaxf(mx[2], mx[3]); mx[2] = mx[3] = m1; }
+            }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TI; ++t) {
                 const float m = row_reduce<(NN >= 16), true>(mx[t]);
                 // rows 1..3 (the three vector-key chunks) share one softmax: fetch their row results (wave-uniform lanes)
                 float v1, v2, v3;
@@ -884,9 +890,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 sr[t] = ex[t];
             }
             if (TPC == 4) { const float s = (sr[0] + sr[1]) + (sr[2] + sr[3]); sr[0] = sr[1] = sr[2] = sr[3] = s; }
-            if (TPC == 2) { const float s0 = sr[0] + sr[1], s1 = sr[2] + sr[3]; sr[0] = sr[1] = s0; sr[2] = sr[3] = s1; }
+            if (TPC == 2) {
+                const float s0 = sr[0] + sr[1]; sr[0] = sr[1] = s0;
+                if (TI == 4) { const float s1 = sr[2] + sr[3]; sr[2] = sr[3] = s1; }
+            }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TI; ++t) {
                 const float sm_ = row_reduce<(NN >= 16), false>(sr[t]);
                 float s1, s2, s3;
                 if (NN >= 16) { s1 = lane_bcast(sm_, 16); s2 = lane_bcast(sm_, 32); s3 = lane_bcast(sm_, 48); }
@@ -922,7 +931,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
         }
         float pi_pre[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // centre's own p_i (second block of Vp, :133), fetched a tile phase early
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < TI; ++t) {
             const TileCtx tc = PF ? tcn : tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
             if (t % TPC == 0) {
 #pragma unroll
@@ -1195,20 +1204,27 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
         hipLaunchKernelGGL(k_node16<false>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
 }
 
-template <int WPB, bool PF, bool F16, bool HY = false>
-static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
-                          const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks) {
-    const int A = 64 / lw.nn;
+template <int NN, int WPB, bool PF, bool F16, bool HY, int TI>
+static void launch_edge_k(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo, const float* rec_nb,
+                          const float* rec_cen, const float* p_state, float* Z, int max_blocks) {
+    constexpr int A = 16 * TI / NN;
     const int n_work = (N1 + A - 1) / A;
     int blocks = ((n_work + 7) / 8 + WPB - 1) / WPB * 8;   // per-XCD share of the work items, WPB per workgroup, x 8 XCDs
     if (blocks > max_blocks) blocks = max_blocks / 8 * 8;
     if (blocks < 8) blocks = 8;
-    const dim3 grid(blocks), block(WPB * 64);
+    hipLaunchKernelGGL((k_edge<NN, WPB, PF, F16, HY, TI>), dim3(blocks), dim3(WPB * 64), 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen,
+                       p_state, Z);
+}
+
+// FINE = false: 64-row work items for every nn; FINE = true: the finest work item that still holds whole centres
+template <int WPB, bool PF, bool F16, bool HY = false, bool FINE = false>
+static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
+                          const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks) {
     switch (lw.nn) {
-        case 8: hipLaunchKernelGGL((k_edge<8, WPB, PF, F16, HY>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
-        case 16: hipLaunchKernelGGL((k_edge<16, WPB, PF, F16, HY>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
-        case 32: hipLaunchKernelGGL((k_edge<32, WPB, PF, F16, HY>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
-        default: hipLaunchKernelGGL((k_edge<64, WPB, PF, F16, HY>), grid, block, 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen, p_state, Z); break;
+        case 8: launch_edge_k<8, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks); break;
+        case 16: launch_edge_k<16, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks); break;
+        case 32: launch_edge_k<32, WPB, PF, F16, HY, FINE ? 2 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks); break;
+        default: launch_edge_k<64, WPB, PF, F16, HY, 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks); break;
     }
 }
 
@@ -1228,7 +1244,8 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
         else launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
     } else {
         if (n_work >= 2048) launch_edge_t<12, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
-        else launch_edge_t<8, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);   // 63 KB of constants: one workgroup per CU
+        else launch_edge_t<8, false, true, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);   // 63 KB of constants: one
+                                                                                                   // workgroup per CU; fine work items
     }
 }
 
