@@ -18,7 +18,10 @@ IO_SOURCE = "pesto_io.cpp"
 IO_OUT = os.path.join(HERE, "libpesto_io.so")
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent f32 adds/muls of the edge kernel into v_pk_*_f32 and pays for it with
 # ~5x more v_mov_b32 shuffles than it saves (665 -> 138 v_mov, mul+add re-fused into v_fmac) - measured +% in DESIGN.md
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
+# -ffp-contract=on: mul+add fuse only within a source expression (front-end decision), not wherever the back-end finds a
+# pair (HIP's default "fast"). The template instantiations of one kernel (tiles per work item, waves per workgroup) then round
+# identically, so a structure gives the same bits alone, in a batch or as a trajectory frame; no measurable cost.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize", "-ffp-contract=on"]
 # developer variants: PESTO_EXTRA_CXXFLAGS="-DPESTO_PROFILE_PHASES" PESTO_LIB_TAG=prof -> libpesto_hip_prof.so (selected at
 # run time with PESTO_LIB=<path>); the default build is what ships
 EXTRA = os.environ.get("PESTO_EXTRA_CXXFLAGS", "").split()
