@@ -480,3 +480,17 @@ def test_knn_on_real_chains_matches_reference_topology(fixture):
     _check_same_neighbours(ids, g["ids_topk"].astype(np.int64), g["X"])
     z = m.forward_segments(g["X"], ids, onehot(g["q_idx"], 30), g["res_of_atom"], g["z"].shape[0])
     assert np.abs(z - g["z"]).max() < 1e-4
+
+
+def test_batch_equals_singles_bitwise_across_kernel_instantiations():
+    """A 16.8k-atom batch runs every layer on the full-size kernels (12-wave workgroups, 4 tiles per work item); its members
+    alone run on the small-launch instantiations (8 waves, 1-2 tiles per item). Same bits either way (-ffp-contract=on)."""
+    from pesto_amd.topology import extract_topology, synthetic_structure
+    m = _model("i_v4_0")
+    structs = []
+    for i in range(6):
+        X, _, q, M = synthetic_structure(2800, 70 + i, n0=30)
+        structs.append((X, extract_topology(X, 64), q, M))
+    zb = m.forward_batch(structs)
+    for i in (0, 3, 5):
+        assert np.array_equal(zb[i], m.forward_batch([structs[i]])[0])
