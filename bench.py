@@ -177,7 +177,19 @@ def main():
         step()
         torch.cuda.synchronize()
         lay_ms.append(model.get_timing())
+    # per-kernel pass (one event between consecutive layer launches): average launch duration of every kernel class
+    model.set_timing(True, per_kernel=True)
+    per_kernel = []
+    for _ in range(5):
+        step()
+        torch.cuda.synchronize()
+        per_kernel.append(model.get_kernel_timing())
     model.set_timing(False)
+    kern = {}
+    for name in per_kernel[0]:
+        n_l = per_kernel[0][name][1]
+        if n_l:
+            kern[name] = {"launches_per_forward": n_l, "avg_launch_ms": float(np.median([pk[name][0] for pk in per_kernel])) / n_l}
     layers_ms = float(np.median([t["layers_ms"] for t in lay_ms]))
     fwd_all = np.array([t["total_ms"] for t in lay_ms])
     fwd_ms = float(np.median(fwd_all))
@@ -187,6 +199,20 @@ def main():
     gbytes = sum(layer_gather_bytes_per_atom(l["nn"]) for l in config["sum"]) * n1
     achieved_tf = flops / (layers_ms * 1e-3) / 1e12
     achieved_gbs = gbytes / (layers_ms * 1e-3) / 1e9
+    # the dominant kernel on its own: k_edge<nn = max> (the edge part of a layer is 2 * 36,376 * nn FLOP and
+    # 532 * nn gather-counted bytes per atom)
+    nn_max = max(l["nn"] for l in config["sum"])
+    dom = kern.get(f"edge_nn{nn_max}")
+    dominant = None
+    if dom:
+        f_l = 2.0 * 36376.0 * nn_max * n1
+        b_l = 532.0 * nn_max * n1
+        t_all = sum(v["avg_launch_ms"] * v["launches_per_forward"] for v in kern.values())
+        dominant = {"kernel": f"k_edge<{nn_max}>", "flops_per_launch": f_l, "avg_launch_ms": dom["avg_launch_ms"],
+                    "achieved": f_l / (dom["avg_launch_ms"] * 1e-3) / 1e12, "unit": "TFLOP/s",
+                    "frac": f_l / (dom["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                    "gather_bytes_per_launch": b_l, "hbm_frac": b_l / (dom["avg_launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "share_of_layer_time": dom["avg_launch_ms"] * dom["launches_per_forward"] / t_all}
     # HBM-side bytes of the layer kernels from the committed PMC passes of this same command (profiles/pmc_collect.sh);
     # only quoted when the workload matches the one the counters were collected on
     traffic = None
@@ -238,6 +264,7 @@ def main():
                          "layers_ms": layers_ms, "forward_ms": fwd_ms,
                          "forward_ms_p10_p90": [float(np.percentile(fwd_all, 10)), float(np.percentile(fwd_all, 90))],
                          "executed_mfma_tflops": executed_mfma_flops(config, n1) / (layers_ms * 1e-3) / 1e12,
+                         "dominant_kernel": dominant, "kernels": kern,
                          "note": "achieved = reference-formulation FLOPs (SURVEY 8d) of all layer launches of one forward / their "
                                  "HIP-event time; peak = dense fp32 MFMA. The kernels execute ~2.5x fewer FLOPs (most of the first edge "
                                  "Linear folded per atom) and run the big GEMMs as f16 hi/lo split MFMA, so frac can exceed 1; "

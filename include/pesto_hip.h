@@ -108,6 +108,10 @@ int pesto_synchronize(pesto_model* m);
  * HIP events on the stream they ran on (bench.py's roofline leg); enable with pesto_set_timing(m, 1). */
 int pesto_set_timing(pesto_model* m, int32_t enabled);
 int pesto_get_timing(pesto_model* m, double* layers_ms, double* total_ms, int32_t* n_layer_launches);
+/* pesto_set_timing(m, 2) additionally records one event between consecutive layer launches; this returns, for the most recent
+ * forward, the summed duration and the launch count per kernel class: [0] node kernel, [1..4] edge kernel with nn = 8, 16, 32, 64
+ * (bench.py's per-kernel roofline). The extra events serialise nothing but cost ~1 us each: not for timed throughput runs. */
+int pesto_get_kernel_timing(pesto_model* m, double ms_sum[5], int32_t launches[5]);
 
 /* replaces: extract_topology (src/data_encoding.py:87-102) + the index half of collate_batch_features (src/dataset.py:100-109)
  * for a concatenated batch: exact k nearest neighbours per atom WITHIN its structure, ascending distance, entries with

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "pesto_last_error", "pesto_blob_size", "pesto_create", "pesto_destroy", "pesto_forward",
     "pesto_workspace_bytes", "pesto_synchronize", "pesto_set_timing", "pesto_get_timing",
     "pesto_stage_embed", "pesto_stage_unpack", "pesto_stage_layer", "pesto_stage_pool", "pesto_knn_collate",
-    "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch",
+    "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch", "pesto_get_kernel_timing",
 ]
 
 _lib = None
@@ -87,6 +87,7 @@ def load():
     lib.pesto_synchronize.argtypes = [c_p]
     lib.pesto_set_timing.argtypes = [c_p, i32]
     lib.pesto_get_timing.argtypes = [c_p, P(ctypes.c_double), P(ctypes.c_double), P(i32)]
+    lib.pesto_get_kernel_timing.argtypes = [c_p, P(ctypes.c_double), P(i32)]
     lib.pesto_knn_collate.argtypes = [c_p, i64, i32, c_p, c_p, i32, c_p, i32, i32, c_p]
     lib.pesto_stage_embed.argtypes = [c_p, i64, c_p, c_p]
     lib.pesto_stage_unpack.argtypes = [c_p, i64, i32, c_p, c_p, i32, c_p, c_p]

@@ -72,6 +72,9 @@ struct pesto_model {
     // timing
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> kev;           // timing level 2: one event between consecutive layer launches
+    std::vector<int> kev_class;            // class of the launch that follows kev[i]: 0 = node, 1..4 = edge nn 8/16/32/64
+    int timing_level = 1;
     int n_layer_launches = 0;
     bool have_timing = false;
 };
@@ -155,16 +158,34 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a) {
     if (a.F > 1) launch_expand_roa(st, (int)a.N, (int)a.R, (int)a.F, a.roa, m->roa_f.as<int>(), err_ptr(m));
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[1], st));
     int cur = 0;
+    const bool detail = m->timing && m->timing_level >= 2 && m->impl == 2;
+    size_t kevi = 0;
+    auto mark = [&](int cls) -> hipError_t {      // event in front of the next layer launch (detail timing only)
+        if (!detail) return hipSuccess;
+        if (kevi == m->kev.size()) {
+            hipEvent_t e;
+            if (hipError_t rc = hipEventCreate(&e)) return rc;
+            m->kev.push_back(e); m->kev_class.push_back(cls);
+        }
+        m->kev_class[kevi] = cls;
+        return hipEventRecord(m->kev[kevi++], st);
+    };
+    auto nn_class = [](int nn) { return nn == 8 ? 1 : nn == 16 ? 2 : nn == 32 ? 3 : 4; };
     if (m->impl == 2) {
         // per layer: node kernel (finish layer l-1, write layer l's records) then edge kernel; state updated in place
         for (int l = 0; l < m->cfg.n_layers; ++l) {
+            HIP_TRY(mark(0));
             launch_node(st, m->W, l > 0 ? &m->img.layers[l - 1] : nullptr, &m->img.layers[l], N1, q[0], p[0], m->zrec.as<float>(),
                         m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->edge_variant);
+            HIP_TRY(mark(nn_class(m->cfg.nn[l])));
             launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(),
                         m->rec_cen.as<float>(), p[0], m->zrec.as<float>(), m->edge_blocks, m->edge_variant);
         }
+        HIP_TRY(mark(0));
         launch_node(st, m->W, &m->img.layers[m->cfg.n_layers - 1], nullptr, N1, q[0], p[0], m->zrec.as<float>(), m->rec_nb.as<float>(),
                     m->rec_cen.as<float>(), m->edge_variant);
+        HIP_TRY(mark(-1));
+        if (detail) { m->kev.resize(kevi); m->kev_class.resize(kevi); }
     } else {
         for (int l = 0; l < m->cfg.n_layers; ++l) {
             launch_layer_v1(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), q[cur], p[cur], q[cur ^ 1], p[cur ^ 1]);
@@ -234,6 +255,7 @@ int pesto_destroy(pesto_model* m) {
     (void)hipDeviceSynchronize();
     debug_print_phase_cycles();
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : m->kev) if (e) (void)hipEventDestroy(e);
     if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
                       &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa})
@@ -259,6 +281,7 @@ int pesto_synchronize(pesto_model* m) {
 int pesto_set_timing(pesto_model* m, int32_t enabled) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     m->timing = enabled != 0;
+    m->timing_level = enabled >= 2 ? 2 : 1;
     m->have_timing = false;
     return 0;
 }
@@ -274,6 +297,22 @@ int pesto_get_timing(pesto_model* m, double* layers_ms, double* total_ms, int32_
     if (layers_ms) *layers_ms = a;
     if (total_ms) *total_ms = b;
     if (n_layer_launches) *n_layer_launches = m->n_layer_launches;
+    return 0;
+}
+
+int pesto_get_kernel_timing(pesto_model* m, double ms_sum[5], int32_t launches[5]) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (!m->have_timing || m->timing_level < 2 || m->kev.size() < 2) return fail(PESTO_ERR_STATE, "no forward timed at level 2 (pesto_set_timing(m, 2))");
+    if (!ms_sum || !launches) return fail(PESTO_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipEventSynchronize(m->kev.back()));
+    for (int c = 0; c < 5; ++c) { ms_sum[c] = 0.0; launches[c] = 0; }
+    for (size_t i = 0; i + 1 < m->kev.size(); ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, m->kev[i], m->kev[i + 1]));
+        const int c = m->kev_class[i];
+        if (c >= 0 && c < 5) { ms_sum[c] += ms; launches[c] += 1; }
+    }
     return 0;
 }
 

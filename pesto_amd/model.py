@@ -418,8 +418,15 @@ class Model:
         return qr, pr, z
 
     # ------------------------------------------------------------------ timing hooks (bench.py)
-    def set_timing(self, enabled=True):
-        _lib.check(_lib.load().pesto_set_timing(self._ensure(), 1 if enabled else 0))
+    def set_timing(self, enabled=True, per_kernel=False):
+        _lib.check(_lib.load().pesto_set_timing(self._ensure(), (2 if per_kernel else 1) if enabled else 0))
+
+    def get_kernel_timing(self):
+        """{class: (summed ms, launches)} of the most recent forward timed with set_timing(True, per_kernel=True)."""
+        ms, n = (ctypes.c_double * 5)(), (ctypes.c_int32 * 5)()
+        _lib.check(_lib.load().pesto_get_kernel_timing(self._ensure(), ms, n))
+        names = ("node", "edge_nn8", "edge_nn16", "edge_nn32", "edge_nn64")
+        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
 
     def get_timing(self):
         a, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
