@@ -64,6 +64,7 @@ struct pesto_model {
     int edge_variant = 0;                  // PESTO_EDGE_VARIANT: 0 = hybrid f16-split (shipped), 1 = exact fp32 MFMA, 5 = full-record f16-split
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     DevBuf knn_off;                       // structure offsets of the last pesto_knn_collate call
+    DevBuf knn_grids, knn_cnt, knn_cur, knn_cell, knn_sorted;   // cell grid of the large structures (pesto_knn_collate)
     DevBuf col_meta, col_ids, col_roa;    // pesto_forward_batch: per-structure table, collated ids / residue columns
     DevBuf dmax, roa_f;                   // per-frame max(D) words; residue column per atom of a frame batch
     std::vector<float> pack;              // host packing buffer for strided host frames
@@ -258,7 +259,7 @@ int pesto_destroy(pesto_model* m) {
     for (auto& e : m->kev) if (e) (void)hipEventDestroy(e);
     if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
-                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa})
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa, &m->knn_grids, &m->knn_cnt, &m->knn_cur, &m->knn_cell, &m->knn_sorted})
         b->release();
     delete m;
     return 0;
@@ -450,21 +451,41 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
         if (struct_offsets[s + 1] <= struct_offsets[s]) return fail(PESTO_ERR_INVALID, "empty or unordered structure %d", s);
     HIP_TRY(hipSetDevice(m->device));
     const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
-    if (m->knn_off.ensure((size_t)(n_struct + 1) * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    // structures of at least knn_cell_min() atoms go through a cell grid (O(N) instead of O(N^2)); each owns one block ("slot") of
+    // the cell arrays. The slot table travels behind the offsets in the same device buffer.
+    std::vector<int> host_tab((size_t)2 * n_struct + 1);
+    int n_slots = 0;
+    const bool brute = getenv("PESTO_KNN_BRUTE") != nullptr;
+    for (int s = 0; s <= n_struct; ++s) host_tab[s] = struct_offsets[s];
+    for (int s = 0; s < n_struct; ++s)
+        host_tab[n_struct + 1 + s] = (!brute && struct_offsets[s + 1] - struct_offsets[s] >= knn_cell_min()) ? n_slots++ : -1;
+    const int use_grid = n_slots > 0;
+    if (m->knn_off.ensure(host_tab.size() * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    if (use_grid) {
+        const size_t cells = (size_t)n_slots * knn_cells_per_struct();
+        if (m->knn_grids.ensure((size_t)n_struct * knn_grid_struct_bytes()) || m->knn_cnt.ensure(cells * 4) || m->knn_cur.ensure(cells * 4) ||
+            m->knn_cell.ensure((size_t)n_total * 4) || m->knn_sorted.ensure((size_t)n_total * 16))
+            return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    }
+    auto knn_launch = [&](hipStream_t s_, const float* Xd, void* out) {
+        launch_knn_collate(s_, (int)n_total, n_struct, m->knn_off.as<int>(), Xd, k, out, ids_kind, use_grid, m->knn_off.as<int>() + n_struct + 1,
+                           m->knn_grids.p, m->knn_cnt.as<int>(),
+                           m->knn_cur.as<int>(), m->knn_cell.as<int>(), m->knn_sorted.p);
+    };
     if (ptr_kind == PESTO_PTR_DEVICE) {
         hipStream_t st = (hipStream_t)stream;
-        HIP_TRY(hipMemcpyAsync(m->knn_off.p, struct_offsets, (size_t)(n_struct + 1) * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));     // the offsets array is the caller's host memory: finish the copy before returning
-        launch_knn_collate(st, (int)n_total, n_struct, m->knn_off.as<int>(), X, k, ids_out, ids_kind);
+        HIP_TRY(hipMemcpyAsync(m->knn_off.p, host_tab.data(), host_tab.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));     // host_tab is a local: finish the copy before returning
+        knn_launch(st, X, ids_out);
         HIP_TRY(hipGetLastError());
         return 0;
     }
     if (ptr_kind != PESTO_PTR_HOST) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     if (m->in_X.ensure((size_t)n_total * 12) || m->in_ids.ensure((size_t)n_total * KMAX * id_sz)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
-    HIP_TRY(hipMemcpyAsync(m->knn_off.p, struct_offsets, (size_t)(n_struct + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->knn_off.p, host_tab.data(), host_tab.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->in_X.p, X, (size_t)n_total * 12, hipMemcpyHostToDevice, st));
-    launch_knn_collate(st, (int)n_total, n_struct, m->knn_off.as<int>(), m->in_X.as<float>(), k, m->in_ids.p, ids_kind);
+    knn_launch(st, m->in_X.as<float>(), m->in_ids.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ids_out, m->in_ids.p, (size_t)n_total * KMAX * id_sz, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

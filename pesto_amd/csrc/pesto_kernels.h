@@ -20,7 +20,15 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
                  const float* Z, float* rec_nb, float* rec_cen, int variant);
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant);
-void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, void* ids_out, int ids_kind);
+// k-NN + collate; with use_grid the structures of at least knn_cell_min() atoms are searched through a uniform cell grid
+// (buffers: slots n_struct ints = block of the cell arrays per structure or -1, grids n_struct * knn_grid_struct_bytes(), cell_cnt /
+// cell_cur n_slots * knn_cells_per_struct() ints, cell_of n_total ints, sorted n_total float4), smaller ones by brute force; identical
+// results either way
+void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, void* ids_out, int ids_kind,
+                        int use_grid, const int* slots, void* grids, int* cell_cnt, int* cell_cur, int* cell_of, void* sorted);
+size_t knn_grid_struct_bytes();
+int knn_cell_min();
+int knn_cells_per_struct();
 // meta: device array of {int off, roff, n, r, k; long long idoff} per structure (32 bytes each, see k_collate)
 void launch_collate(hipStream_t st, int n_total, int n_struct, const void* meta, const void* ids_raw, int ids_kind, const int* roa_raw,
                     int* ids_out, int* roa_out, int* err_flag);

@@ -554,41 +554,202 @@ __device__ __forceinline__ unsigned long long bitonic_step(unsigned long long v,
     return take_min ? (v < o ? v : o) : (v < o ? o : v);
 }
 
+// ---- cell grid for large structures (N_s >= KNN_CELL_MIN): brute force is O(N_s^2); with a uniform grid a query only meets the
+// atoms of the (2s+1)^3 cells around it. Exactness is kept by a completeness test: every atom outside that block is at least
+// s*h away from the query, so once the k-th best key is an unmasked distance strictly below s*h the k best are final; otherwise
+// the block grows (s = 2, 3, 5, 8, ... until it covers the grid). Keys, tie-breaks and the merge network are those of the
+// brute-force path, so both paths return identical tables.
+constexpr int KNN_CELL_MIN = 1024;        // structures at least this large use the grid (measured: 2x at N = 3,000, 5.7x at N = 20,000)
+constexpr int KNN_GRID_MAX = 32;          // cells per axis (h grows beyond 32 * 4.5 A = 144 A of extent)
+constexpr int KNN_MAXC = KNN_GRID_MAX * KNN_GRID_MAX * KNN_GRID_MAX;
+struct KnnGrid { float minx, miny, minz, h, inv_h; int nx, ny, nz, use, slot; };   // use = 0: brute force for this structure;
+                                                                                  // slot = which block of the cell arrays it owns
+
+__global__ __launch_bounds__(256) void k_grid_setup(int n_struct, const int* __restrict__ offsets, const int* __restrict__ slots,
+                                                    const float* __restrict__ X, KnnGrid* __restrict__ grids, int* __restrict__ cell_cnt) {
+    const int s = blockIdx.x;
+    const int s0 = offsets[s], s1 = offsets[s + 1];
+    __shared__ float red[6][256];
+    __shared__ KnnGrid gsh;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const bool big = slots[s] >= 0;
+    if (big)
+        for (int i = s0 + threadIdx.x; i < s1; i += 256)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float v = X[3 * (size_t)i + c]; mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { red[c][threadIdx.x] = mn[c]; red[3 + c][threadIdx.x] = mx[c]; }
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                red[c][threadIdx.x] = fminf(red[c][threadIdx.x], red[c][threadIdx.x + off]);
+                red[3 + c][threadIdx.x] = fmaxf(red[3 + c][threadIdx.x], red[3 + c][threadIdx.x + off]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        KnnGrid g;
+        g.use = 0; g.slot = slots[s]; g.nx = g.ny = g.nz = 0; g.minx = g.miny = g.minz = 0.f; g.h = g.inv_h = 0.f;
+        if (big) {
+            const float ex = red[3][0] - red[0][0], ey = red[4][0] - red[1][0], ez = red[5][0] - red[2][0];
+            const float ext = fmaxf(ex, fmaxf(ey, ez));
+            if (ext == ext && ext < 1e30f) {          // finite coordinates only; otherwise stay on the brute-force path
+                g.h = fmaxf(4.5f, ext / (float)KNN_GRID_MAX * 1.0001f);
+                g.inv_h = 1.0f / g.h;
+                g.minx = red[0][0]; g.miny = red[1][0]; g.minz = red[2][0];
+                g.nx = min(KNN_GRID_MAX, (int)(ex * g.inv_h) + 1); g.ny = min(KNN_GRID_MAX, (int)(ey * g.inv_h) + 1);
+                g.nz = min(KNN_GRID_MAX, (int)(ez * g.inv_h) + 1);
+                g.use = 1;
+            }
+        }
+        grids[s] = g;
+        gsh = g;
+    }
+    __syncthreads();
+    if (gsh.use) {
+        const int nc = gsh.nx * gsh.ny * gsh.nz;
+        for (int c = threadIdx.x; c <= nc; c += 256) cell_cnt[(size_t)gsh.slot * (KNN_MAXC + 1) + c] = 0;
+    }
+}
+
+__device__ __forceinline__ int knn_cell_of(const KnnGrid& g, float x, float y, float z) {
+    const int cx = min(g.nx - 1, max(0, (int)((x - g.minx) * g.inv_h)));
+    const int cy = min(g.ny - 1, max(0, (int)((y - g.miny) * g.inv_h)));
+    const int cz = min(g.nz - 1, max(0, (int)((z - g.minz) * g.inv_h)));
+    return (cz * g.ny + cy) * g.nx + cx;
+}
+__device__ __forceinline__ int knn_struct_of(int i, int n_struct, const int* __restrict__ offsets) {
+    int lo = 0, hi = n_struct;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_grid_count(int n_total, int n_struct, const int* __restrict__ offsets, const float* __restrict__ X,
+                                                    const KnnGrid* __restrict__ grids, int* __restrict__ cell_cnt, int* __restrict__ cell_of) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    const int s = knn_struct_of(i, n_struct, offsets);
+    const KnnGrid g = grids[s];
+    if (!g.use) return;
+    const int c = knn_cell_of(g, X[3 * (size_t)i], X[3 * (size_t)i + 1], X[3 * (size_t)i + 2]);
+    cell_of[i] = c;
+    atomicAdd(&cell_cnt[(size_t)g.slot * (KNN_MAXC + 1) + c], 1);
+}
+
+// exclusive scan of one structure's cell counts (one workgroup per structure; <= 32,768 cells) -> cell_start, cursor copy
+__global__ __launch_bounds__(1024) void k_grid_scan(const KnnGrid* __restrict__ grids, int* __restrict__ cell_cnt, int* __restrict__ cell_cur) {
+    const int s = blockIdx.x;
+    const KnnGrid g = grids[s];
+    if (!g.use) return;
+    const int nc = g.nx * g.ny * g.nz;
+    int* cnt = cell_cnt + (size_t)g.slot * (KNN_MAXC + 1);
+    int* cur = cell_cur + (size_t)g.slot * (KNN_MAXC + 1);
+    __shared__ int part[1024];
+    const int per = (nc + 1023) / 1024;
+    const int c0 = threadIdx.x * per, c1 = min(nc, c0 + per);
+    int sum = 0;
+    for (int c = c0; c < c1; ++c) sum += cnt[c];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the per-thread sums
+        const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int c = c0; c < c1; ++c) { const int n = cnt[c]; cnt[c] = run; cur[c] = run; run += n; }
+    if (threadIdx.x == 1023) cnt[nc] = part[1023];
+}
+
+// atoms in cell order: (x, y, z, local index) so that a candidate is one 16-byte load
+__global__ __launch_bounds__(256) void k_grid_scatter(int n_total, int n_struct, const int* __restrict__ offsets, const float* __restrict__ X,
+                                                      const KnnGrid* __restrict__ grids, const int* __restrict__ cell_of,
+                                                      int* __restrict__ cell_cur, float4* __restrict__ sorted) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    const int s = knn_struct_of(i, n_struct, offsets);
+    if (!grids[s].use) return;
+    const int pos = atomicAdd(&cell_cur[(size_t)grids[s].slot * (KNN_MAXC + 1) + cell_of[i]], 1);
+    sorted[offsets[s] + pos] = make_float4(X[3 * (size_t)i], X[3 * (size_t)i + 1], X[3 * (size_t)i + 2], __int_as_float(i - offsets[s]));
+}
+
+// merge one chunk of 64 candidate keys (one per lane, WORST = none) into the running top-64 (ascending across lanes)
+__device__ __forceinline__ unsigned long long knn_merge(unsigned long long top, unsigned long long key, int lane) {
+    const unsigned long long worst = ((unsigned long long)__shfl((unsigned)(top >> 32), 63) << 32) | __shfl((unsigned)top, 63);
+    if (__ballot(key < worst) == 0ull) return top;        // nothing in this chunk beats the current k-th best
+    for (int size = 2; size <= 64; size <<= 1)
+        for (int jj = size >> 1; jj > 0; jj >>= 1) key = bitonic_step(key, lane, jj, (lane & size) == 0 || size == 64);
+    // 64 smallest of (top ascending, chunk ascending): min(top[l], chunk[63-l]) is bitonic; merge it ascending
+    const unsigned long long rev = shfl_xor64(key, 63);
+    unsigned long long m = top < rev ? top : rev;
+    for (int jj = 32; jj > 0; jj >>= 1) m = bitonic_step(m, lane, jj, true);
+    return m;
+}
+__device__ __forceinline__ unsigned long long knn_key(float rx, float ry, float rz, int local_index) {
+    const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz)));
+    const unsigned masked = d < 1e-2f ? 1u : 0u;
+    return ((unsigned long long)((masked << 31) | __float_as_uint(d)) << 32) | (unsigned)local_index;   // d >= 0: bit 31 is free
+}
+
 template <typename IdT>
 __global__ __launch_bounds__(256) void k_knn_collate(int n_total, int n_struct, const int* __restrict__ offsets,
-                                                     const float* __restrict__ X, int k, IdT* __restrict__ ids_out) {
+                                                     const float* __restrict__ X, int k, IdT* __restrict__ ids_out,
+                                                     const KnnGrid* __restrict__ grids, const int* __restrict__ cell_start,
+                                                     const float4* __restrict__ sorted) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_total) return;
-    // structure of atom i: binary search in offsets (wave-uniform)
-    int lo = 0, hi = n_struct;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
-    const int s0 = offsets[lo], s1 = offsets[lo + 1];
+    const int st = knn_struct_of(i, n_struct, offsets);      // wave-uniform
+    const int s0 = offsets[st], s1 = offsets[st + 1];
     const float xi = X[3 * (size_t)i], yi = X[3 * (size_t)i + 1], zi = X[3 * (size_t)i + 2];
     const unsigned long long WORST = ~0ull;
     unsigned long long top = WORST;                 // lane l holds the (l+1)-th best key so far, ascending across lanes
-    for (int base = s0; base < s1; base += 64) {
-        const int j = base + lane;
-        unsigned long long key = WORST;
-        if (j < s1) {
-            const float rx = X[3 * (size_t)j] - xi, ry = X[3 * (size_t)j + 1] - yi, rz = X[3 * (size_t)j + 2] - zi;
-            const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz)));
-            const unsigned masked = d < 1e-2f ? 1u : 0u;
-            key = ((unsigned long long)((masked << 31) | __float_as_uint(d)) << 32) | (unsigned)(j - s0);   // d >= 0: bit 31 is free
+    const int knn = min(k, s1 - s0);
+    bool done = false;
+    if (grids && grids[st].use) {
+        const KnnGrid g = grids[st];
+        const int* cs = cell_start + (size_t)g.slot * (KNN_MAXC + 1);
+        const int cx = min(g.nx - 1, max(0, (int)((xi - g.minx) * g.inv_h)));
+        const int cy = min(g.ny - 1, max(0, (int)((yi - g.miny) * g.inv_h)));
+        const int cz = min(g.nz - 1, max(0, (int)((zi - g.minz) * g.inv_h)));
+        for (int s = 2; !done; s = s < 3 ? 3 : (s * 8 + 4) / 5) {       // 2, 3, 5, 8, 13, ...
+            top = WORST;
+            const int x0 = max(0, cx - s), x1 = min(g.nx - 1, cx + s);
+            for (int zc = max(0, cz - s); zc <= min(g.nz - 1, cz + s); ++zc)
+                for (int yc = max(0, cy - s); yc <= min(g.ny - 1, cy + s); ++yc) {
+                    const int row = (zc * g.ny + yc) * g.nx;
+                    const int a0 = cs[row + x0], a1 = cs[row + x1 + 1];      // one contiguous run of the sorted atoms
+                    for (int base = a0; base < a1; base += 64) {
+                        unsigned long long key = WORST;
+                        if (base + lane < a1) {
+                            const float4 c = sorted[s0 + base + lane];
+                            key = knn_key(c.x - xi, c.y - yi, c.z - zi, __float_as_int(c.w));
+                        }
+                        top = knn_merge(top, key, lane);
+                    }
+                }
+            const bool whole = cx - s <= 0 && cy - s <= 0 && cz - s <= 0 && cx + s >= g.nx - 1 && cy + s >= g.ny - 1 && cz + s >= g.nz - 1;
+            // k-th best: an unmasked distance strictly inside the radius the block guarantees (small margin for the rounding of
+            // the cell assignment) -> no atom outside the block can enter or tie
+            const unsigned long long kth = ((unsigned long long)__shfl((unsigned)(top >> 32), knn - 1) << 32) | __shfl((unsigned)top, knn - 1);
+            const unsigned hi32 = (unsigned)(kth >> 32);
+            const bool ok = kth != WORST && !(hi32 >> 31) && __uint_as_float(hi32) < (float)s * g.h * 0.9999f;
+            done = whole || ok;
         }
-        const unsigned long long worst = ((unsigned long long)__shfl((unsigned)(top >> 32), 63) << 32) | __shfl((unsigned)top, 63);
-        if (__ballot(key < worst) == 0ull) continue;        // nothing in this chunk beats the current k-th best
-        // sort the chunk ascending (bitonic sort over 64 lanes)
-        for (int size = 2; size <= 64; size <<= 1)
-            for (int jj = size >> 1; jj > 0; jj >>= 1) key = bitonic_step(key, lane, jj, (lane & size) == 0 || size == 64);
-        // 64 smallest of (top ascending, chunk ascending): min(top[l], chunk[63-l]) is bitonic; merge it ascending
-        const unsigned long long rev = shfl_xor64(key, 63);
-        unsigned long long m = top < rev ? top : rev;
-        for (int jj = 32; jj > 0; jj >>= 1) m = bitonic_step(m, lane, jj, true);
-        top = m;
+    }
+    if (!done) {
+        top = WORST;
+        for (int base = s0; base < s1; base += 64) {
+            const int j = base + lane;
+            unsigned long long key = WORST;
+            if (j < s1) key = knn_key(X[3 * (size_t)j] - xi, X[3 * (size_t)j + 1] - yi, X[3 * (size_t)j + 2] - zi, j - s0);
+            top = knn_merge(top, key, lane);
+        }
     }
     // lanes 0..knn-1 hold the neighbours in ascending order; zero padding beyond (dataset.py:100,109)
-    const int knn = min(k, s1 - s0);
     long long id = 0;
     if (lane < knn) id = (long long)(unsigned)(top & 0xffffffffu) + s0 + 1;
     if (lane < KMAX) ids_out[(size_t)i * KMAX + lane] = (IdT)id;
@@ -657,12 +818,27 @@ void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z,
     hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, N, R, n_out, z, roa, p_out, bf_out, err_flag);
 }
 
-void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, void* ids_out, int ids_kind) {
+// grid buffers (all device): slots [n_struct] (block of the cell arrays a structure owns, -1 = brute force), grids [n_struct],
+// cell_cnt / cell_cur [n_slots * (KNN_MAXC + 1)] ints, cell_of [n_total] ints, sorted [n_total] float4. use_grid = 0 skips the grid.
+void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, void* ids_out, int ids_kind,
+                        int use_grid, const int* slots, void* grids, int* cell_cnt, int* cell_cur, int* cell_of, void* sorted) {
+    if (use_grid) {
+        hipLaunchKernelGGL(k_grid_setup, dim3(n_struct), dim3(256), 0, st, n_struct, offsets, slots, X, (KnnGrid*)grids, cell_cnt);
+        hipLaunchKernelGGL(k_grid_count, dim3((n_total + 255) / 256), dim3(256), 0, st, n_total, n_struct, offsets, X, (const KnnGrid*)grids, cell_cnt, cell_of);
+        hipLaunchKernelGGL(k_grid_scan, dim3(n_struct), dim3(1024), 0, st, (const KnnGrid*)grids, cell_cnt, cell_cur);
+        hipLaunchKernelGGL(k_grid_scatter, dim3((n_total + 255) / 256), dim3(256), 0, st, n_total, n_struct, offsets, X, (const KnnGrid*)grids, cell_of, cell_cur,
+                           (float4*)sorted);
+    }
+    const KnnGrid* gp = use_grid ? (const KnnGrid*)grids : nullptr;
     const dim3 grid((n_total + 3) / 4), block(256);
     if (ids_kind == PESTO_IDS_INT64)
-        hipLaunchKernelGGL(k_knn_collate<long long>, grid, block, 0, st, n_total, n_struct, offsets, X, k, (long long*)ids_out);
+        hipLaunchKernelGGL(k_knn_collate<long long>, grid, block, 0, st, n_total, n_struct, offsets, X, k, (long long*)ids_out, gp, cell_cnt, (const float4*)sorted);
     else
-        hipLaunchKernelGGL(k_knn_collate<int>, grid, block, 0, st, n_total, n_struct, offsets, X, k, (int*)ids_out);
+        hipLaunchKernelGGL(k_knn_collate<int>, grid, block, 0, st, n_total, n_struct, offsets, X, k, (int*)ids_out, gp, cell_cnt, (const float4*)sorted);
 }
+
+size_t knn_grid_struct_bytes() { return sizeof(KnnGrid); }
+int knn_cell_min() { return KNN_CELL_MIN; }
+int knn_cells_per_struct() { return KNN_MAXC + 1; }
 
 }  // namespace pesto

@@ -494,3 +494,43 @@ def test_batch_equals_singles_bitwise_across_kernel_instantiations():
     zb = m.forward_batch(structs)
     for i in (0, 3, 5):
         assert np.array_equal(zb[i], m.forward_batch([structs[i]])[0])
+
+
+# ---------------------------------------------------------------------------------------------- k-NN cell grid (large structures)
+def _knn_both_paths(m, X, sizes, monkeypatch):
+    monkeypatch.delenv("PESTO_KNN_BRUTE", raising=False)
+    grid = m.knn_collate(X, sizes)
+    monkeypatch.setenv("PESTO_KNN_BRUTE", "1")
+    brute = m.knn_collate(X, sizes)
+    monkeypatch.delenv("PESTO_KNN_BRUTE", raising=False)
+    return grid, brute
+
+
+def test_knn_cell_grid_equals_brute_force(monkeypatch):
+    """Structures of >= 1024 atoms are searched through a uniform cell grid; the table must be the brute-force one, bit for bit:
+    protein-like cloud, a mixed batch (large + small members), a flat slab (one cell layer), two dense blobs far apart (most
+    cells empty, blocks must grow), and atoms on a line."""
+    from pesto_amd.topology import synthetic_cloud
+    m = _model("i_v4_0")
+    rng = np.random.default_rng(3)
+    cloud = synthetic_cloud(6000, 21)
+    slab = synthetic_cloud(5000, 22); slab[:, 2] *= 0.02
+    blobs = np.concatenate([synthetic_cloud(2500, 23), synthetic_cloud(2500, 24) + 400.0]).astype(np.float32)
+    line = np.zeros((4500, 3), np.float32); line[:, 0] = np.arange(4500) * 1.3 + rng.uniform(0, 0.3, 4500)
+    for X, sizes in ((cloud, [6000]), (np.concatenate([cloud[:4200], cloud[4200:5400], cloud[5400:], slab]), [4200, 1200, 600, 5000]),
+                     (slab, [5000]), (blobs, [5000]), (line, [4500]), (cloud[:1024], [1024])):
+        grid, brute = _knn_both_paths(m, np.ascontiguousarray(X, np.float32), sizes, monkeypatch)
+        assert np.array_equal(grid, brute)
+        assert grid.min() >= 1 and grid.max() <= X.shape[0]
+
+
+def test_knn_cell_grid_vs_host_contract_and_forward(monkeypatch):
+    from pesto_amd.topology import extract_topology, synthetic_structure
+    m = _model("i_v4_0")
+    X, _, q, M = synthetic_structure(5000, 31, n0=30)
+    ids = m.knn_collate(X, [5000])
+    _check_same_neighbours(ids, extract_topology(X, 64) + 1, X)        # host contract (k-d tree above 4096 atoms)
+    roa = M.argmax(1).astype(np.int32)
+    z = m.forward_segments(X, ids, q, roa, M.shape[1])
+    zo = _oracle("i_v4_0").forward_segments(X, ids.astype(np.int32), q, roa, M.shape[1])
+    assert np.abs(z - zo).max() < 1e-4
