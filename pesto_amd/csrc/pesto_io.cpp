@@ -383,21 +383,78 @@ int64_t residue_columns(const Atoms& a, std::vector<int32_t>& col) {
 }
 
 // ------------------------------------------------------------------------------------------------ writing
+// ---- number formatting without printf (the writer is the slowest step of the native apply_model chain otherwise)
+// "{:>Wd}"
+void append_int(std::string& out, long long v, int width) {
+    char buf[24];
+    int n = 0;
+    const bool neg = v < 0;
+    unsigned long long u = neg ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (neg) buf[n++] = '-';
+    for (int i = n; i < width; ++i) out.push_back(' ');
+    while (n) out.push_back(buf[--n]);
+}
+// "{:W.Df}" of a value that came from a float32 (D <= 3): v * 10^D has at most 24 + 10 significant bits, so the product is exact
+// in double and rint (ties to even) reproduces printf's correctly rounded decimal, including exact ties. Anything else
+// (non-finite, huge) goes through snprintf.
+void append_fixed(std::string& out, double v, int width, int decimals) {
+    static const double P10[4] = {1.0, 10.0, 100.0, 1000.0};
+    if (!(std::fabs(v) < 1e12) || decimals > 3) {
+        char buf[64];
+        snprintf(buf, sizeof buf, "%*.*f", width, decimals, v);
+        out += buf;
+        return;
+    }
+    const bool neg = std::signbit(v);
+    unsigned long long n = (unsigned long long)std::llrint(std::fabs(v) * P10[decimals]);
+    char buf[32];
+    int k = 0;
+    for (int d = 0; d < decimals; ++d) { buf[k++] = (char)('0' + n % 10); n /= 10; }
+    if (decimals) buf[k++] = '.';
+    do { buf[k++] = (char)('0' + n % 10); n /= 10; } while (n);
+    if (neg) buf[k++] = '-';
+    for (int i = k; i < width; ++i) out.push_back(' ');
+    while (k) out.push_back(buf[--k]);
+}
+void append_left(std::string& out, const std::string& t, size_t width) {      // "{:<Ws}"
+    out += t;
+    for (size_t i = t.size(); i < width; ++i) out.push_back(' ');
+}
+void append_right(std::string& out, const std::string& t, size_t width) {     // "{:>Ws}"
+    for (size_t i = t.size(); i < width; ++i) out.push_back(' ');
+    out += t;
+}
+
 // save_pdb(split_by_chain(structure), path): src/structure_io.py:96-123
+// line = "{:<6s}{:>5d} {:<4s} {:>3s} {:1s}{:>4d}    {:8.3f}{:8.3f}{:8.3f}{:6.2f}{:6.2f}          {:<2s}  "
 void format_pdb(const Atoms& a, const std::vector<float>& bf, std::string& out) {
     out.clear();
-    char line[256];
+    out.reserve(a.size() * 82 + 64);
     for (const auto& su : split_by_chain(a)) {
         const std::string head = su.first.substr(0, su.first.find(':'));
         const char c = head.empty() ? ' ' : head[0];
-        int64_t serial = 0;
+        long long serial = 0;
         for (size_t i : su.second) {
             const double b = bf.empty() ? 0.0 : (double)bf[i];
-            snprintf(line, sizeof line, "%-6s%5lld %-4s %3s %c%4lld    %8.3f%8.3f%8.3f%6.2f%6.2f          %-2s  \n",
-                     a.het[i] == 'A' ? "ATOM" : "HETATM", (long long)++serial, a.name[i].c_str(), a.resname[i].c_str(), c,
-                     (long long)a.resid[i], (double)a.xyz[3 * i], (double)a.xyz[3 * i + 1], (double)a.xyz[3 * i + 2], b, b,
-                     a.element[i].c_str());
-            out += line;
+            out += a.het[i] == 'A' ? "ATOM  " : "HETATM";
+            append_int(out, ++serial, 5);
+            out.push_back(' ');
+            append_left(out, a.name[i], 4);
+            out.push_back(' ');
+            append_right(out, a.resname[i], 3);
+            out.push_back(' ');
+            out.push_back(c);
+            append_int(out, a.resid[i], 4);
+            out += "    ";
+            append_fixed(out, (double)a.xyz[3 * i], 8, 3);
+            append_fixed(out, (double)a.xyz[3 * i + 1], 8, 3);
+            append_fixed(out, (double)a.xyz[3 * i + 2], 8, 3);
+            append_fixed(out, b, 6, 2);
+            append_fixed(out, b, 6, 2);
+            out += "          ";
+            append_left(out, a.element[i], 2);
+            out += "  \n";
         }
         out += "TER\n";
     }

@@ -131,3 +131,24 @@ def test_parse_errors_are_reported():
     water = "HETATM    1  O   HOH A   1       1.000   2.000   3.000  1.00  0.00           O  \n"
     with pytest.raises(sio.PestoIOError):
         Structure.parse_pdb(water).preprocess()
+
+
+def test_writer_number_formatting_equals_python_format():
+    """The writer formats numbers without printf; every line must equal the reference's Python format string
+    (src/structure_io.py:118) for awkward float32 values: exact decimal ties, tiny negatives, -0.0, wide numbers."""
+    rng = np.random.default_rng(0)
+    special = np.array([0.125, -0.125, 0.375, 2.5e-4, -2.5e-4, -0.0, 0.0, 0.0005, -0.0005, 0.9995, 9.9995, 99.995, 999.9995, -999.9995, 1234.5675,
+                        9999.9995, -9999.9995, 12345.678, 0.005, 0.015, 0.025, 0.035, 0.045, 1.005, 2.675, 1e-7, -1e-7, 123456.7], np.float32)
+    vals = np.concatenate([special, rng.uniform(-500, 500, 3000).astype(np.float32), (rng.integers(-99999, 99999, 2000) / 1000.0).astype(np.float32),
+                           (rng.integers(0, 2000, 1000) / 2000.0).astype(np.float32)])
+    n = vals.size
+    xyz = np.stack([vals, np.roll(vals, 1), np.roll(vals, 2)], 1).astype(np.float32)
+    bf = np.roll(vals, 3).astype(np.float32)
+    st = {"xyz": xyz, "name": np.array(["CA"] * n), "element": np.array(["C"] * n), "resname": np.array(["ALA"] * n),
+          "resid": np.arange(1, n + 1), "het_flag": np.array(["A"] * n), "chain_name": np.array(["A:0"] * n)}
+    text = sio.Structure.from_dict(st).format_pdb(bf).split("\n")
+    fmt = "{:<6s}{:>5d} {:<4s} {:>3s} {:1s}{:>4d}    {:8.3f}{:8.3f}{:8.3f}{:6.2f}{:6.2f}          {:<2s}  "
+    for i in range(n):
+        want = fmt.format("ATOM", i + 1, "CA", "ALA", "A", i + 1, xyz[i, 0], xyz[i, 1], xyz[i, 2], bf[i], bf[i], "C")
+        assert text[i] == want, (i, text[i], want)
+    assert text[n] == "TER" and text[n + 1] == "END"
