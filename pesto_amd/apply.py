@@ -1,0 +1,71 @@
+"""Bulk form of the reference's inference loop (apply_model.ipynb cell 6, interfaceome/apply_model.py:57-82):
+PDB files in, per-residue interface probabilities (and b-factor PDB files) out.
+
+The reference runs one structure at a time behind a DataLoader with 8 worker processes. Here the host stages (native read /
+clean / encode, native write; both release the GIL inside libpesto_io.so) run in a thread pool, and the GPU stage takes several
+structures per launch: collated coordinates -> GPU k-NN (pesto_knn_collate) -> forward -> GPU sigmoid + b-factor expansion.
+Structures that fail to parse are reported and skipped, as the reference's try/except does.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from .structure_io import PestoIOError, Structure
+
+
+def _load(path, n0):
+    s = Structure.read_pdb(path).preprocess()
+    X, q, roa, R = s.encode(n0)
+    return s, X, q, roa, R
+
+
+def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=24576, workers=8, on_error=print):
+    """Returns {path: p} with p = sigmoid(z) as numpy [R, n_out] for every structure that could be processed.
+    write=True also saves ``path[:-4] + suffix.format(i)`` for each output channel i (apply_model.ipynb:157-166).
+    ``model``: a pesto_amd.Model on a GPU; max_atoms: atoms per launch (about 24k fills an MI355X)."""
+    import torch
+    n0 = model.config["em"]["N0"]
+    dev = torch.device("cuda", model._gpu)
+    results = {}
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        loads = [(p, pool.submit(_load, p, n0)) for p in pdb_filepaths]
+        writes = []
+
+        def flush(group):
+            if not group:
+                return
+            sizes = [len(g[1]) for g in group]
+            X = torch.from_numpy(np.concatenate([g[2] for g in group])).to(dev)
+            q = torch.from_numpy(np.concatenate([g[3] for g in group])).to(dev)
+            r_off = np.cumsum([0] + [g[5] for g in group])
+            roa = torch.from_numpy(np.concatenate([g[4] + r_off[i] for i, g in enumerate(group)]).astype(np.int32)).to(dev)
+            ids = model.knn_collate(X, sizes)
+            z = model.forward_segments(X, ids, q, roa, int(r_off[-1]))
+            p, bf = model.postprocess(z, roa)
+            p, bf = p.cpu().numpy(), bf.cpu().numpy()
+            a_off = np.cumsum([0] + sizes)
+            for i, (path, s, *_rest) in enumerate(group):
+                results[path] = p[r_off[i]:r_off[i + 1]]
+                if write:
+                    for c in range(bf.shape[0]):
+                        out = path[:-4] + suffix.format(c)
+                        writes.append(pool.submit(s.save_pdb, out, np.ascontiguousarray(bf[c, a_off[i]:a_off[i + 1]])))
+
+        group, atoms = [], 0
+        for path, fut in loads:
+            try:
+                s, X, q, roa, R = fut.result()
+            except (PestoIOError, OSError) as e:
+                if on_error:
+                    on_error(f"error with {path}: {e}")
+                continue
+            if group and atoms + len(s) > max_atoms:
+                flush(group)
+                group, atoms = [], 0
+            group.append((path, s, X, q, roa, R))
+            atoms += len(s)
+        flush(group)
+        for w in writes:
+            w.result()
+    return results

@@ -534,3 +534,36 @@ def test_knn_cell_grid_vs_host_contract_and_forward(monkeypatch):
     z = m.forward_segments(X, ids, q, roa, M.shape[1])
     zo = _oracle("i_v4_0").forward_segments(X, ids.astype(np.int32), q, roa, M.shape[1])
     assert np.abs(z - zo).max() < 1e-4
+
+
+def test_bulk_apply_model_pdb_in_pdb_out(tmp_path):
+    """pesto_amd.apply.apply_model: PDB files -> probabilities + b-factor PDB files, several structures per launch, host stages in
+    threads. Checked against the one-structure-at-a-time chain; an unreadable file is reported and skipped."""
+    import gzip
+    import os
+    from conftest import GOLDEN
+    from pesto_amd.apply import apply_model
+    from pesto_amd.structure_io import Structure
+    m = _model("i_v4_0").to("cuda")
+    paths = []
+    for name in ("7KHT_lipid", "1thf_D", "6I9F"):
+        p = tmp_path / (name + ".pdb")
+        p.write_text(gzip.open(os.path.join(GOLDEN, "pdb", name + ".pdb.gz"), "rt").read())
+        paths.append(str(p))
+    bad = tmp_path / "broken.pdb"
+    bad.write_text("ATOM      1  N   ALA A   1      30.837\n")
+    errors = []
+    res = apply_model(m, paths[:2] + [str(bad)] + paths[2:], max_atoms=4500, workers=4, on_error=errors.append)
+    assert set(res) == set(paths) and len(errors) == 1 and "broken.pdb" in errors[0]
+    for p in paths:
+        s = Structure.read_pdb(p).preprocess()
+        X, q, roa, R = s.encode(30)
+        ids = m.knn_collate(X, [len(s)])
+        z = m.forward_segments(X, ids, q, roa, R)
+        pr, bf = m.postprocess(z, roa)
+        assert res[p].shape == pr.shape and np.abs(res[p] - pr).max() < 1e-5
+        for c in range(5):
+            got = open(p[:-4] + f"_i{c}.pdb").read()
+            assert got.count("\n") == s.format_pdb(bf[c]).count("\n")
+            b_got = np.array([float(l[54:60]) for l in got.split("\n") if l.startswith(("ATOM", "HETATM"))])
+            assert np.abs(b_got - np.round(bf[c].astype(np.float64), 2)).max() < 0.0101
