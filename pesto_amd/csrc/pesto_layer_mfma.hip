@@ -1,18 +1,22 @@
-// pesto_layer_mfma.hip - the state-update layer on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+// pesto_layer_mfma.hip - the state-update layer on the gfx950 matrix cores.
 //
 // Reference math: src/model_operations.py:87-154 (StateUpdate.forward) + :225-242 (StateUpdateLayer.forward).
 // One layer = two kernels:
 //
-//   k_node   per ATOM, batched as MFMA GEMMs over 16-atom column tiles (one wave each):
+//   k_node16 per ATOM, batched as MFMA GEMMs over 16-atom column tiles (four waves per tile):
 //            (finish) q += qpm(Zq), p += ppm(Zp) of the previous layer, sink row reset            (:147-152, :239-240)
 //            (prep)   the first Linear of the three edge MLPs is linear in its 193 inputs
 //                     [d | X_n(i) | q_j | |p_j| | p_i.r | p_j.r]  (:109-116), so its per-atom pieces are computed
 //                     ONCE per atom instead of once per edge (exact algebra, different summation order):
 //                       centre record   U_i = b1 + W[:,1:65] X_n(i),  G_i[c] = W[:,129:161] p_i[c],  Q_i = nqm(X_n(i))
-//                       neighbour record A_j = W[:,65:129] X_n(j),    C_j[c] = W[:,161:193] p_j[c],  p_j
-//   k_edge   per EDGE: h1 = ELU(U_i + w_d d + A_j + sum_c r_c (G_i[c] + C_j[c]))  (VALU + one small MFMA for the
-//            centre terms), layers 2/3 of eqkm/epkm/evm as MFMA chains held in registers, both softmaxes with
-//            wavefront shuffles, attention-weighted sums Zq/Zp written per atom.  (:119-144)
+//                       neighbour record A_j = W[:,65:129] X_n(j)     (shipped "hybrid" path; variants 1 / 5 also store
+//                                        C_j[c] = W[:,161:193] p_j[c], a 2 KB record)
+//   k_edge   per EDGE: h1 = ELU(U_i + sum_c r_c G_i[c] + w_d d + A_j + W[:,161:193] (p_j . r))  - centre terms by one K = 4
+//            fp32 MFMA per block, the p_j . r block per edge on f16-split MFMA from the gathered p_j - then layers 2/3 of
+//            eqkm/epkm/evm as MFMA chains held in registers, both softmaxes with DPP reductions, attention-weighted sums
+//            Zq/Zp written per atom.  (:119-144)
+//   Shipped arithmetic: every large GEMM as f16 hi/lo split on v_mfma_f32_16x16x32_f16 (x.w = xh.wh + xl.wh + xh.wl, fp32
+//   accumulate); k_node / PESTO_EDGE_VARIANT=1 keep everything on exact fp32 v_mfma_f32_16x16x4_f32.
 //
 // MFMA conventions (16x16x4 f32): lane l = (c = l & 15, g = l >> 4).  D[4g + r][c] is register r of lane l.
 // Operands chain without shuffles: a D tile of features (rows 16fb + 4g + r) x edges (cols c) is fed back as the
