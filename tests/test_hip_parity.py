@@ -567,3 +567,14 @@ def test_bulk_apply_model_pdb_in_pdb_out(tmp_path):
             assert got.count("\n") == s.format_pdb(bf[c]).count("\n")
             b_got = np.array([float(l[54:60]) for l in got.split("\n") if l.startswith(("ATOM", "HETATM"))])
             assert np.abs(b_got - np.round(bf[c].astype(np.float64), 2)).max() < 0.0101
+
+
+def test_knn_fewer_columns_than_64():
+    """k < 64: the first k columns are the k nearest, the rest of the 64-column table is zero padding (grid and brute-force paths)."""
+    from pesto_amd.topology import synthetic_cloud
+    m = _model("i_v4_0")
+    for n in (300, 2000):
+        X = synthetic_cloud(n, 77)
+        full = m.knn_collate(X, [n])
+        part = m.knn_collate(X, [n], k=16)
+        assert np.array_equal(part[:, :16], full[:, :16]) and not part[:, 16:].any()
