@@ -35,7 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
-// fp32 -> (hi, lo) f16 pair with x = hi + lo to ~2^-21 relative: hi = rtz16(x), lo = rtz16(x - hi) (the residual is
+// fp32 -> (hi, lo) f16 pair with x = hi + lo to ~2^-21 relative: hi = rn16(x), lo = rn16(x - hi) (the residual is
 // exact in fp32). Two 16-feature blocks (4 + 4 values of this lane) form the 8 k-values one lane feeds to
 // v_mfma_f32_16x16x32_f16. Three MFMAs (hi*hi, lo*hi, hi*lo) then reproduce the fp32 product to ~2^-21.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -43,14 +43,18 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // compiler only emits those from inline asm, and inline asm is invisible to the MFMA hazard recogniser: a register it
 // overwrites may still be read as SrcC by an in-flight MFMA (seen as rare, timing-dependent corruption in a node-kernel
 // variant). Plain convert / subtract / convert costs 3 more VALU per pair and is hazard-checked.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
     const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v[j], v[j + 1]);
-        const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(v[j] - (float)h[0], v[j + 1] - (float)h[1]);
-        hi[j] = (_Float16)h[0]; hi[j + 1] = (_Float16)h[1];
-        lo[j] = (_Float16)l[0]; lo[j + 1] = (_Float16)l[1];
+    for (int j = 0; j < 8; j += 2) {   // pairs, round to nearest (v_cvt_pk_f16_f32 on gfx950): |x - hi| <= 2^-12 |x|, hi + lo carries 2^-22
+        const f32x2 x = {v[j], v[j + 1]};
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 r = x - __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[j] = h[0]; hi[j + 1] = h[1];
+        lo[j] = l[0]; lo[j + 1] = l[1];
     }
 }
 __device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast<const f16x8*>(p); }
