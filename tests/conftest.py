@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built libraries (they are git-ignored): build them once, in-tree (hipcc cross-compiles without a GPU)
+    from pesto_amd import _lib, structure_io
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(structure_io.LIB_PATH)):
+        from pesto_amd.csrc import build as native_build
+        native_build.build(verbose=False)
 
 
 def golden(name):
