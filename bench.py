@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 PEAK_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix = vector peak
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
+PEAK_F16_TFLOPS = 2500.0  # dense f16 MFMA (the pipe the split GEMMs run on)
 
 
 def layer_flops_per_atom(nn):
@@ -264,6 +265,7 @@ def main():
                          "layers_ms": layers_ms, "forward_ms": fwd_ms,
                          "forward_ms_p10_p90": [float(np.percentile(fwd_all, 10)), float(np.percentile(fwd_all, 90))],
                          "executed_mfma_tflops": executed_mfma_flops(config, n1) / (layers_ms * 1e-3) / 1e12,
+                         "executed_frac_of_f16_peak": executed_mfma_flops(config, n1) / (layers_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS,
                          "dominant_kernel": dominant, "kernels": kern,
                          "note": "achieved = reference-formulation FLOPs (SURVEY 8d) of all layer launches of one forward / their "
                                  "HIP-event time; peak = dense fp32 MFMA. The kernels execute ~2.5x fewer FLOPs (most of the first edge "
