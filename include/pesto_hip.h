@@ -34,8 +34,23 @@ typedef enum pesto_status {
     PESTO_ERR_INVALID = -1,   /* bad argument / config / blob size */
     PESTO_ERR_HIP = -2,       /* a HIP runtime call failed */
     PESTO_ERR_NOMEM = -3,
-    PESTO_ERR_STATE = -4      /* debug entry point called out of order */
+    PESTO_ERR_STATE = -4,     /* debug entry point called out of order */
+    PESTO_ERR_RANGE = -5      /* PESTO_PRECISION_F16_SPLIT only: an activation left the f16 range (z has been filled with NaN) */
 } pesto_status;
+
+/* Arithmetic of the state-update layers (the reference computes in fp32 throughout, src/model_operations.py:87-154).
+ *   F16_SPLIT : every large GEMM as three v_mfma_f32_16x16x32_f16 products of f16 hi/lo pairs (x = hi + lo), fp32 accumulate:
+ *               ~22-bit mantissa, but the f16 EXPONENT range - activations beyond +-65504 cannot be represented. The kernels
+ *               detect that (range guard); the result is then NaN everywhere and, where the call synchronises, PESTO_ERR_RANGE.
+ *   FP32      : everything on exact fp32 MFMA (v_mfma_f32_16x16x4_f32), no range limit, about half the speed.
+ *   AUTO      : F16_SPLIT, and a forward whose range guard fired is repeated on the FP32 kernels before the call returns
+ *               (the reference's trained i_v3_1, model/save/i_v3_1_2021-05-28_12-40, needs this: its states reach 4e5).
+ *               Costs one 4-byte read-back + stream synchronisation per call. Default. */
+typedef enum pesto_precision {
+    PESTO_PRECISION_AUTO = 0,
+    PESTO_PRECISION_F16_SPLIT = 1,
+    PESTO_PRECISION_FP32 = 2
+} pesto_precision;
 
 /* replaces: the config dict consumed by Model.__init__ (model/model.py:7-30, model/config.py:25-63).
  * Ns=32, Nh=2, Nk=3, pool Nh=4, N1=32 are fixed (true for every run shipped with the reference). */
@@ -46,6 +61,7 @@ typedef struct pesto_config {
     int32_t n_out;                 /* config["dm"]["N2"] */
     int32_t em_depth;              /* 3 = Linear-ELU-Linear-ELU-Linear (model/model.py:10-16); 1 = single Linear (i_v3_1) */
     int32_t dm_depth;              /* same for the decoder (model/model.py:24-30) */
+    int32_t precision;             /* pesto_precision; no reference counterpart (torch computes in fp32) */
 } pesto_config;
 
 typedef struct pesto_model pesto_model;
@@ -64,16 +80,37 @@ int pesto_blob_size(const pesto_config* cfg, int64_t* n_floats);
 int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weights, int device, pesto_model** out);
 int pesto_destroy(pesto_model* m);
 
+/* change the precision policy of an existing handle (takes effect with the next call) / read it back together with the number
+ * of launch sequences run so far and how many of them AUTO repeated on the fp32 kernels */
+int pesto_set_precision(pesto_model* m, int32_t precision);
+int pesto_get_status(const pesto_model* m, int32_t* precision, int64_t* n_forward, int64_t* n_fp32_rerun);
+
 /* replaces: Model.forward(X, ids_topk, q0, M)  (model/model.py:32-52).
  * ptr_kind: PESTO_PTR_HOST (library stages H2D/D2H itself) or PESTO_PTR_DEVICE (all five buffers on
- * the model's device). stream: a hipStream_t. With device pointers the call is asynchronous on exactly
- * that stream (NULL = HIP's default stream, which is what torch.cuda.current_stream() is by default);
- * with host pointers NULL selects the model's own stream and the call returns after z has been copied back.
+ * the model's device). stream: a hipStream_t. With device pointers the work is queued on exactly that stream
+ * (NULL = HIP's default stream, which is what torch.cuda.current_stream() is by default): under PESTO_PRECISION_AUTO the
+ * call then waits for it, checks the flags word (bad ids / residue columns -> PESTO_ERR_INVALID, range overflow -> fp32
+ * re-run) and returns; under F16_SPLIT / FP32 it returns at once and nothing is checked (bad inputs or an overflow make
+ * every logit NaN). With host pointers NULL selects the model's own stream and the call returns after z has been copied back.
+ * A handle owns ONE workspace: calls on different streams are ordered after one another through an event, never concurrent.
  * No allocation happens on this path once the grow-only workspace has seen a batch of this size. */
 int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k,
                   const float* X, const void* ids_topk, int32_t ids_kind,
                   const float* q0, const int32_t* res_of_atom,
                   float* z_out, int32_t ptr_kind, void* stream);
+
+/* replaces: the reference's bulk inference loops, which call Model.forward ONCE PER STRUCTURE (apply_model.ipynb:139-167,
+ * interfaceome/apply_model.py:57-82, profiling.py:84-108), for n_struct structures laid out as one collated batch
+ * (X, ids_topk, q0, res_of_atom exactly as for pesto_forward; ids_topk e.g. from pesto_knn_collate with the same offsets).
+ * Structure s owns atoms [struct_offsets[s], struct_offsets[s+1]) (HOST array, n_struct + 1 entries). One launch sequence
+ * for the whole batch, but the two places where the reference's forward couples the atoms of a call - the wrap-around of
+ * zero-padded neighbour slots to the LAST atom and the global max(D) of the coincident-atom fix-up
+ * (src/model_operations.py:8-12) - act per structure, so every structure gets the result of its own call, independent
+ * of its batch mates. Pointer / stream / precision rules as pesto_forward. */
+int pesto_forward_structures(pesto_model* m, int64_t N, int64_t R, int32_t k, int32_t n_struct, const int32_t* struct_offsets,
+                             const float* X, const void* ids_topk, int32_t ids_kind,
+                             const float* q0, const int32_t* res_of_atom,
+                             float* z_out, int32_t ptr_kind, void* stream);
 
 /* replaces: the per-frame loop of the reference's MD analysis (md_analysis/apply_model_md.ipynb cell 6):
  *     for i in frames: z_i = model(X_traj[:, i], ids_topk, q, M)        # ids_topk, q, M of frame 0 for every frame
@@ -92,11 +129,19 @@ int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_
  * HOST pointers, one entry per structure b: X[b] float32 [N_b,3]; ids_topk0[b] [N_b,k_b] 0-BASED within the structure, as
  * extract_topology returns them (k_b = min(64, N_b)); q0[b] [N_b,n0]; res_of_atom[b] int32 [N_b] (column of the structure's
  * own mask, R_b residues); z_out[b] float32 [R_b,n_out]. The arrays are copied back to back and collated ON THE DEVICE
- * (offset + 1-based ids zero-padded to 64 columns, residue columns offset); the result is exactly the reference's forward on
- * the collated batch (one global max(D), padding wraps to the last atom of the batch). Returns after every z_out[b] is filled. */
+ * (offset + 1-based ids zero-padded to 64 columns, residue columns offset). batch_mode:
+ *   PESTO_BATCH_COLLATED    exactly the reference's forward on the collated batch (training-style batches, src/dataset.py:91-112):
+ *                           ONE max(D) for the whole batch and zero-padded neighbour slots wrap to the LAST atom of the batch
+ *                           (src/model_operations.py:8-12) - a structure's result depends on its batch mates when it has fewer
+ *                           than 64 atoms or coincident atoms;
+ *   PESTO_BATCH_INDEPENDENT each structure as in its own call, which is what the reference's bulk inference loops do (one
+ *                           structure per forward): max(D) and the wrap target are per structure, so results do not depend on
+ *                           how structures were grouped into launches (what sharding over GPUs relies on).
+ * Returns after every z_out[b] is filled. */
+enum { PESTO_BATCH_COLLATED = 0, PESTO_BATCH_INDEPENDENT = 1 };
 int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, const int64_t* R, const int32_t* k,
                         const float* const* X, const void* const* ids_topk0, int32_t ids_kind, const float* const* q0,
-                        const int32_t* const* res_of_atom, float* const* z_out, void* stream);
+                        const int32_t* const* res_of_atom, float* const* z_out, int32_t batch_mode, void* stream);
 
 /* bytes of device workspace a batch of (N, R) needs (ownership: SURVEY 8b) */
 int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* bytes);
@@ -128,6 +173,13 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
  * loop can keep every structure's result on the GPU and copy back once. */
 int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, const int32_t* res_of_atom, float* p_out, float* bfactor_out,
                       int32_t ptr_kind, void* stream);
+
+/* ---- test hooks ----
+ * Debug twins of the shipped kernels, selected per handle (the parity tests run every stage through each of them):
+ * layer_kernels 0 = shipped (hybrid first layer; arithmetic per the precision policy), 1 = reference-formulation fp32 VALU
+ * kernel (LDS-tiled, no MFMA), 5 = f16-split MFMA with full 2 KB neighbour records (the round-1 design);
+ * knn_brute_force != 0: pesto_knn_collate searches every structure by brute force instead of the cell grid. */
+int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_force);
 
 /* ---- per-stage entry points (HOST pointers), used by tests/ to pin each stage against the oracle ----
  * replaces: em.forward (model/model.py:34) */

@@ -13,6 +13,10 @@ LIB_PATH = os.environ.get("PESTO_LIB") or os.path.join(_HERE, "csrc", "libpesto_
 
 PTR_HOST, PTR_DEVICE = 0, 1
 IDS_INT32, IDS_INT64 = 32, 64
+BATCH_COLLATED, BATCH_INDEPENDENT = 0, 1
+# enum pesto_precision
+PRECISIONS = {"auto": 0, "f16_split": 1, "fp32": 2}
+ERR_RANGE = -5
 
 
 class PestoConfig(ctypes.Structure):
@@ -24,10 +28,18 @@ class PestoConfig(ctypes.Structure):
         ("n_out", ctypes.c_int32),
         ("em_depth", ctypes.c_int32),
         ("dm_depth", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
     ]
 
 
-def make_c_config(config):
+def precision_code(precision):
+    try:
+        return PRECISIONS[str(precision).lower()]
+    except KeyError:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}") from None
+
+
+def make_c_config(config, precision="auto"):
     c = normalise(config)
     cc = PestoConfig()
     cc.n0 = c["em"]["N0"]
@@ -37,6 +49,7 @@ def make_c_config(config):
     cc.n_out = c["dm"]["N2"]
     cc.em_depth = c["em_depth"]
     cc.dm_depth = c["dm_depth"]
+    cc.precision = precision_code(precision)
     return cc
 
 
@@ -46,13 +59,15 @@ ABI_SYMBOLS = [
     "pesto_workspace_bytes", "pesto_synchronize", "pesto_set_timing", "pesto_get_timing",
     "pesto_stage_embed", "pesto_stage_unpack", "pesto_stage_layer", "pesto_stage_pool", "pesto_knn_collate",
     "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch", "pesto_get_kernel_timing",
+    "pesto_set_precision", "pesto_get_status", "pesto_debug_select", "pesto_forward_structures",
 ]
 
 _lib = None
 
 
 class PestoError(RuntimeError):
-    pass
+    """code: the negative pesto_status the library returned (None when raised by the Python layer)."""
+    code = None
 
 
 def load():
@@ -80,8 +95,12 @@ def load():
     lib.pesto_create.argtypes = [P(PestoConfig), c_p, i64, ctypes.c_int, P(c_p)]
     lib.pesto_destroy.argtypes = [c_p]
     lib.pesto_forward.argtypes = [c_p, i64, i64, i32, c_p, c_p, i32, c_p, c_p, c_p, i32, c_p]
+    lib.pesto_forward_structures.argtypes = [c_p, i64, i64, i32, i32, c_p, c_p, c_p, i32, c_p, c_p, c_p, i32, c_p]
     lib.pesto_forward_frames.argtypes = [c_p, i64, i64, i32, i64, c_p, i64, i64, c_p, i32, c_p, c_p, c_p, i32, i32, c_p]
-    lib.pesto_forward_batch.argtypes = [c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p, c_p, c_p]
+    lib.pesto_forward_batch.argtypes = [c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p, c_p, i32, c_p]
+    lib.pesto_set_precision.argtypes = [c_p, i32]
+    lib.pesto_get_status.argtypes = [c_p, P(i32), P(i64), P(i64)]
+    lib.pesto_debug_select.argtypes = [c_p, i32, i32]
     lib.pesto_postprocess.argtypes = [c_p, i64, i64, c_p, c_p, c_p, c_p, i32, c_p]
     lib.pesto_workspace_bytes.argtypes = [c_p, i64, i64, P(i64)]
     lib.pesto_synchronize.argtypes = [c_p]
@@ -103,4 +122,6 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().pesto_last_error()
-        raise PestoError(f"libpesto_hip error {rc}: {msg.decode() if msg else '?'}")
+        err = PestoError(f"libpesto_hip error {rc}: {msg.decode() if msg else '?'}")
+        err.code = rc
+        raise err

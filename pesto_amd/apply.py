@@ -41,7 +41,7 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
             r_off = np.cumsum([0] + [g[5] for g in group])
             roa = torch.from_numpy(np.concatenate([g[4] + r_off[i] for i, g in enumerate(group)]).astype(np.int32)).to(dev)
             ids = model.knn_collate(X, sizes)
-            z = model.forward_segments(X, ids, q, roa, int(r_off[-1]))
+            z = model.forward_segments(X, ids, q, roa, int(r_off[-1]), sizes=sizes)    # one call per structure, semantically
             p, bf = model.postprocess(z, roa)
             p, bf = p.cpu().numpy(), bf.cpu().numpy()
             a_off = np.cumsum([0] + sizes)

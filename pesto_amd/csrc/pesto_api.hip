@@ -59,15 +59,25 @@ struct pesto_model {
     // workspace (library owns weights + a grow-only workspace; no allocation once warm)
     DevBuf ids_s, geo, q_a, p_a, q_b, p_b, pool_a, seg, z, flags;
     DevBuf rec_nb, rec_cen, zrec;          // MFMA path: per-atom neighbour / centre records and attention sums
-    int impl = 2;                          // 2 = MFMA layer (default), 1 = LDS-tiled VALU layer (PESTO_IMPL=v1)
+    int precision = PESTO_PRECISION_AUTO;  // pesto_config.precision / pesto_set_precision
+    int impl = 2;                          // 2 = MFMA layer (default), 1 = LDS-tiled VALU layer (pesto_debug_select: debug twin)
     int edge_blocks = 512;                 // persistent workgroups of the edge kernel (2 per CU)
-    int edge_variant = 0;                  // PESTO_EDGE_VARIANT: 0 = hybrid f16-split (shipped), 1 = exact fp32 MFMA, 5 = full-record f16-split
+    int fast_variant = 0;                  // kernels of the f16-split path: 0 = hybrid (shipped), 5 = full-record (debug twin)
+    bool knn_brute = false;                // pesto_debug_select: brute-force k-NN for every structure
+    int64_t n_forward = 0, n_rerun = 0;    // launch sequences run / repeated on the exact fp32 kernels after a range overflow
+    // every launch sequence uses the ONE workspace below: sequences on different streams are ordered through this event
+    hipEvent_t ws_ev = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_pending = false;
+    int* h_flags = nullptr;                // pinned host copy of the flags word (read back without a pageable staging copy)
+    DevBuf col_seg, col_segend;            // pesto_forward_batch: structure of every atom, end offset of every structure
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     DevBuf knn_off;                       // structure offsets of the last pesto_knn_collate call
     DevBuf knn_grids, knn_cnt, knn_cur, knn_cell, knn_sorted;   // cell grid of the large structures (pesto_knn_collate)
     DevBuf col_meta, col_ids, col_roa;    // pesto_forward_batch: per-structure table, collated ids / residue columns
     DevBuf dmax, roa_f;                   // per-frame max(D) words; residue column per atom of a frame batch
     std::vector<float> pack;              // host packing buffer for strided host frames
+    std::vector<int> seg_host;            // structure end offsets of the last pesto_forward_structures call (H2D source)
     // state left by pesto_stage_unpack for pesto_stage_layer
     int64_t stage_N = -1;
     // timing
@@ -113,12 +123,39 @@ int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
 unsigned* dmax_ptr(pesto_model* m) { return m->dmax.as<unsigned>(); }
 int* err_ptr(pesto_model* m) { return m->flags.as<int>() + 1; }
 
-int check_device_flag(pesto_model* m, hipStream_t st) {
-    int flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, err_ptr(m), sizeof(int), hipMemcpyDeviceToHost, st));
+// Workspace ordering (one workspace per handle, any number of caller streams): a sequence on stream st first waits for the
+// event the previous sequence recorded if that one ran on a different stream, and records the event when it has been queued.
+int begin_sequence(pesto_model* m, hipStream_t st) {
+    if (m->ws_pending && m->ws_stream != st) HIP_TRY(hipStreamWaitEvent(st, m->ws_ev, 0));
+    return 0;
+}
+int end_sequence(pesto_model* m, hipStream_t st) {
+    HIP_TRY(hipEventRecord(m->ws_ev, st));
+    m->ws_stream = st;
+    m->ws_pending = true;
+    return 0;
+}
+struct Sequence {      // every entry point that touches the workspace holds one for its duration
+    pesto_model* m;
+    hipStream_t st;
+    int rc;
+    Sequence(pesto_model* m_, hipStream_t st_) : m(m_), st(st_), rc(begin_sequence(m_, st_)) {}
+    ~Sequence() { if (rc == 0) (void)end_sequence(m, st); }
+    Sequence(const Sequence&) = delete;
+    Sequence& operator=(const Sequence&) = delete;
+};
+
+// synchronises st; *flag_out (optional) receives the flags word: bit 0 bad ids, bit 1 bad residue column, bit 2 f16-range overflow
+int check_device_flag(pesto_model* m, hipStream_t st, int* flag_out = nullptr, int ignore = 0) {
+    HIP_TRY(hipMemcpyAsync(m->h_flags, err_ptr(m), sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const int flag = *m->h_flags;
+    if (flag_out) *flag_out = flag;
     if (flag & 1) return fail(PESTO_ERR_INVALID, "ids_topk contains an index outside [0, N]");
     if (flag & 2) return fail(PESTO_ERR_INVALID, "res_of_atom contains an index outside [0, R)");
+    if ((flag & 4) && !(ignore & 4))
+        return fail(PESTO_ERR_RANGE, "an activation left the f16 range of the split-MFMA path (z is NaN): use PESTO_PRECISION_AUTO or "
+                                     "PESTO_PRECISION_FP32");
     return 0;
 }
 
@@ -134,28 +171,36 @@ struct FwdArgs {
     const float* q0 = nullptr;
     const int* roa = nullptr;
     float* z_out = nullptr;     // [F*R, n_out]
+    // ragged structures with separate-call semantics (pesto_forward_batch, PESTO_BATCH_INDEPENDENT; F = 1 only)
+    int n_seg = 0;
+    const int* seg_of_atom = nullptr;
+    const int* seg_end = nullptr;
 };
 
 // the launch sequence of Model.forward (model/model.py:32-52) on stream st
-int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a) {
+// exact: the state-update layers on the exact fp32 MFMA kernels instead of the f16-split ones
+int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     const int64_t NT = a.N * a.F, RT = a.R * a.F;
     const int N1 = (int)NT + 1;
+    const int edge_variant = exact ? 1 : m->fast_variant;
+    const size_t n_dmax = a.seg_of_atom ? (size_t)a.n_seg : (size_t)a.F;
     float* q[2] = {m->q_a.as<float>(), m->q_b.as<float>()};
     float* p[2] = {m->p_a.as<float>(), m->p_b.as<float>()};
-    if (m->dmax.ensure((size_t)a.F * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    if (m->dmax.ensure(n_dmax * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    m->n_forward += 1;
     const int* roa = a.roa;
     if (a.F > 1) {
         if (m->roa_f.ensure((size_t)NT * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
         roa = m->roa_f.as<int>();
     }
     HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
-    HIP_TRY(hipMemsetAsync(m->dmax.p, 0, (size_t)a.F * 4, st));
+    HIP_TRY(hipMemsetAsync(m->dmax.p, 0, n_dmax * 4, st));
     HIP_TRY(hipMemsetAsync(q[0], 0, S * sizeof(float), st));                       // sink row of q (model_operations.py:17)
     HIP_TRY(hipMemsetAsync(p[0], 0, (size_t)N1 * 96 * sizeof(float), st));         // p0 = zeros (model.py:37)
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[0], st));
     launch_embed(st, m->W, m->img.model.em, (int)NT, (int)a.N, m->cfg.n0, a.q0, q[0]);
     launch_unpack(st, (int)a.N, (int)a.F, a.k, a.X, a.xs_frame, a.xs_atom, a.ids, a.ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(),
-                  dmax_ptr(m), err_ptr(m));
+                  dmax_ptr(m), err_ptr(m), a.seg_of_atom, a.seg_end);
     if (a.F > 1) launch_expand_roa(st, (int)a.N, (int)a.R, (int)a.F, a.roa, m->roa_f.as<int>(), err_ptr(m));
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[1], st));
     int cur = 0;
@@ -177,14 +222,14 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a) {
         for (int l = 0; l < m->cfg.n_layers; ++l) {
             HIP_TRY(mark(0));
             launch_node(st, m->W, l > 0 ? &m->img.layers[l - 1] : nullptr, &m->img.layers[l], N1, q[0], p[0], m->zrec.as<float>(),
-                        m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->edge_variant);
+                        m->rec_nb.as<float>(), m->rec_cen.as<float>(), edge_variant, err_ptr(m));
             HIP_TRY(mark(nn_class(m->cfg.nn[l])));
             launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(),
-                        m->rec_cen.as<float>(), p[0], m->zrec.as<float>(), m->edge_blocks, m->edge_variant);
+                        m->rec_cen.as<float>(), p[0], m->zrec.as<float>(), m->edge_blocks, edge_variant, err_ptr(m));
         }
         HIP_TRY(mark(0));
         launch_node(st, m->W, &m->img.layers[m->cfg.n_layers - 1], nullptr, N1, q[0], p[0], m->zrec.as<float>(), m->rec_nb.as<float>(),
-                    m->rec_cen.as<float>(), m->edge_variant);
+                    m->rec_cen.as<float>(), edge_variant, err_ptr(m));
         HIP_TRY(mark(-1));
         if (detail) { m->kev.resize(kevi); m->kev_class.resize(kevi); }
     } else {
@@ -206,6 +251,31 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a) {
 
 int check_model(const pesto_model* m) { return m ? 0 : fail(PESTO_ERR_INVALID, "null model handle"); }
 
+// One forward under the handle's precision policy, then flag handling.
+//   FP32      : exact kernels. F16_SPLIT: split kernels. AUTO: split kernels; if the range guard fired, the same inputs again
+//               on the exact kernels (the inputs are still in place).
+//   sync_check: read the flags word back (synchronises st) and turn bad inputs / a range overflow into an error code. Host-pointer
+//               calls always do (they wait for the D2H copy anyway; `after_run` queues that copy). Device-pointer calls do in
+//               AUTO mode only - F16_SPLIT and FP32 stay asynchronous and unchecked there (bad inputs or an overflow still make
+//               every logit NaN, written by the pool kernel).
+template <typename AfterRun>
+int forward_policy(pesto_model* m, hipStream_t st, const FwdArgs& a, bool sync_check, AfterRun after_run) {
+    const bool exact_first = m->precision == PESTO_PRECISION_FP32 || m->impl != 2;
+    if (int rc = run_forward(m, st, a, exact_first)) return rc;
+    if (int rc = after_run()) return rc;
+    if (!sync_check) return 0;
+    int flag = 0;
+    const bool may_rerun = m->precision == PESTO_PRECISION_AUTO && !exact_first;
+    if (int rc = check_device_flag(m, st, &flag, may_rerun ? 4 : 0)) return rc;
+    if ((flag & 4) && may_rerun) {
+        m->n_rerun += 1;
+        if (int rc = run_forward(m, st, a, true)) return rc;
+        if (int rc = after_run()) return rc;
+        return check_device_flag(m, st);
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -221,7 +291,7 @@ int pesto_blob_size(const pesto_config* cfg, int64_t* n_floats) {
 int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weights, int device, pesto_model** out) {
     if (!out) return fail(PESTO_ERR_INVALID, "out is null");
     *out = nullptr;
-    if (!config_ok(cfg)) return fail(PESTO_ERR_INVALID, "invalid pesto_config (nn must be 8/16/32/64, depths 1 or 3, n_out <= 32)");
+    if (!config_ok(cfg)) return fail(PESTO_ERR_INVALID, "invalid pesto_config (nn must be 8/16/32/64, depths 1 or 3, n_out <= 32, precision a pesto_precision)");
     const int64_t need = host_schema(*cfg).total;
     if (!weights || n_weights != need)
         return fail(PESTO_ERR_INVALID, "weight blob has %lld floats, config needs %lld", (long long)n_weights, (long long)need);
@@ -233,10 +303,10 @@ int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weight
     m->cfg = *cfg;
     m->device = device;
     m->img = build_device_image(*cfg, weights);
-    if (const char* impl = getenv("PESTO_IMPL")) m->impl = (strcmp(impl, "v1") == 0 || strcmp(impl, "1") == 0) ? 1 : 2;
-    if (const char* ev = getenv("PESTO_EDGE_VARIANT")) { const int v = atoi(ev); m->edge_variant = (v == 1 || v == 5) ? v : 0; }
-    if (const char* eb = getenv("PESTO_EDGE_BLOCKS")) { int v = atoi(eb); if (v > 0) m->edge_blocks = v; }
+    m->precision = cfg->precision;
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ws_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&m->h_flags, 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&m->W, m->img.data.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(m->W, m->img.data.data(), m->img.data.size() * sizeof(float), hipMemcpyHostToDevice);
     for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&m->ev[i]);
@@ -255,11 +325,13 @@ int pesto_destroy(pesto_model* m) {
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     (void)hipDeviceSynchronize();
     debug_print_phase_cycles();
+    if (m->ws_ev) (void)hipEventDestroy(m->ws_ev);
+    if (m->h_flags) (void)hipHostFree(m->h_flags);
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : m->kev) if (e) (void)hipEventDestroy(e);
     if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
-                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa, &m->knn_grids, &m->knn_cnt, &m->knn_cur, &m->knn_cell, &m->knn_sorted})
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa, &m->knn_grids, &m->knn_cnt, &m->knn_cur, &m->knn_cell, &m->knn_sorted, &m->col_seg, &m->col_segend})
         b->release();
     delete m;
     return 0;
@@ -276,6 +348,31 @@ int pesto_synchronize(pesto_model* m) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int pesto_set_precision(pesto_model* m, int32_t precision) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (precision != PESTO_PRECISION_AUTO && precision != PESTO_PRECISION_F16_SPLIT && precision != PESTO_PRECISION_FP32)
+        return fail(PESTO_ERR_INVALID, "precision must be PESTO_PRECISION_AUTO, _F16_SPLIT or _FP32");
+    m->precision = precision;
+    return 0;
+}
+
+int pesto_get_status(const pesto_model* m, int32_t* precision, int64_t* n_forward, int64_t* n_fp32_rerun) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (precision) *precision = m->precision;
+    if (n_forward) *n_forward = m->n_forward;
+    if (n_fp32_rerun) *n_fp32_rerun = m->n_rerun;
+    return 0;
+}
+
+int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_force) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (layer_kernels != 0 && layer_kernels != 1 && layer_kernels != 5) return fail(PESTO_ERR_INVALID, "layer_kernels must be 0, 1 or 5");
+    m->impl = layer_kernels == 1 ? 1 : 2;
+    m->fast_variant = layer_kernels == 5 ? 5 : 0;
+    m->knn_brute = knn_brute_force != 0;
     return 0;
 }
 
@@ -317,14 +414,14 @@ int pesto_get_kernel_timing(pesto_model* m, double ms_sum[5], int32_t launches[5
     return 0;
 }
 
-int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k, const float* X, const void* ids_topk, int32_t ids_kind,
-                  const float* q0, const int32_t* res_of_atom, float* z_out, int32_t ptr_kind, void* stream) {
-    return pesto_forward_frames(m, N, R, k, 1, X, 3 * N, 3, ids_topk, ids_kind, q0, res_of_atom, z_out, 1, ptr_kind, stream);
-}
+}  // extern "C"
 
-int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_frames, const float* X, int64_t x_frame_stride,
-                         int64_t x_atom_stride, const void* ids_topk, int32_t ids_kind, const float* q0, const int32_t* res_of_atom,
-                         float* z_out, int32_t frames_per_launch, int32_t ptr_kind, void* stream) {
+namespace {
+// pesto_forward / pesto_forward_frames / pesto_forward_structures: n_struct > 0 (one frame only) gives the structures
+// [struct_offsets[s], struct_offsets[s+1]) of the collated batch separate-call semantics (per-structure wrap target and max(D))
+int forward_common(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_frames, const float* X, int64_t x_frame_stride,
+                   int64_t x_atom_stride, const void* ids_topk, int32_t ids_kind, const float* q0, const int32_t* res_of_atom,
+                   float* z_out, int32_t frames_per_launch, int32_t ptr_kind, void* stream, int32_t n_struct, const int32_t* struct_offsets) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || R > N) return fail(PESTO_ERR_INVALID, "bad sizes N=%lld R=%lld", (long long)N, (long long)R);
     if (n_frames < 1) return fail(PESTO_ERR_INVALID, "n_frames=%lld must be >= 1", (long long)n_frames);
@@ -349,14 +446,34 @@ int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_
     const int n_out = m->cfg.n_out;
     FwdArgs a;
     a.N = N; a.R = R; a.k = k; a.ids_kind = ids_kind;
+    if (n_struct > 0) {
+        if (n_frames != 1 || !struct_offsets || struct_offsets[0] != 0 || struct_offsets[n_struct] != N)
+            return fail(PESTO_ERR_INVALID, "struct_offsets must span [0, N] (one frame)");
+        for (int s = 0; s < n_struct; ++s)
+            if (struct_offsets[s + 1] <= struct_offsets[s]) return fail(PESTO_ERR_INVALID, "empty or unordered structure %d", s);
+        if (m->col_seg.ensure((size_t)N * 4) || m->col_segend.ensure((size_t)n_struct * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    }
+    // the structure table is uploaded inside the sequence (it lives in the shared workspace)
+    auto upload_segments = [&](hipStream_t st) -> int {
+        if (n_struct <= 0) return 0;
+        m->seg_host.assign(struct_offsets + 1, struct_offsets + n_struct + 1);
+        HIP_TRY(hipMemcpyAsync(m->col_segend.p, m->seg_host.data(), (size_t)n_struct * 4, hipMemcpyHostToDevice, st));
+        launch_segments(st, (int)N, n_struct, m->col_segend.as<int>(), m->col_seg.as<int>());
+        a.n_seg = n_struct; a.seg_of_atom = m->col_seg.as<int>(); a.seg_end = m->col_segend.as<int>();
+        return 0;
+    };
     if (ptr_kind == PESTO_PTR_DEVICE) {   // stream is taken literally: NULL is HIP's default (null) stream
         a.ids = ids_topk; a.q0 = q0; a.roa = res_of_atom; a.xs_frame = x_frame_stride; a.xs_atom = x_atom_stride;
+        hipStream_t st = (hipStream_t)stream;
+        Sequence seq(m, st);
+        if (seq.rc) return seq.rc;
+        if (int rc = upload_segments(st)) return rc;
         for (int64_t c = 0; c < n_chunks; ++c) {
             const int64_t f0 = c * n_frames / n_chunks;
             a.F = (c + 1) * n_frames / n_chunks - f0;
             a.X = X + f0 * x_frame_stride;
             a.z_out = z_out + f0 * R * n_out;
-            if (int rc = run_forward(m, (hipStream_t)stream, a)) return rc;
+            if (int rc = forward_policy(m, st, a, m->precision == PESTO_PRECISION_AUTO, [] { return 0; })) return rc;
         }
         return 0;
     }
@@ -364,6 +481,9 @@ int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_
     if (m->in_X.ensure((size_t)N * fpl * 3 * 4) || m->in_ids.ensure((size_t)N * k * id_sz) || m->in_q0.ensure((size_t)N * m->cfg.n0 * 4) ||
         m->in_roa.ensure((size_t)N * 4))
         return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    Sequence seq(m, st);
+    if (seq.rc) return seq.rc;
+    if (int rc = upload_segments(st)) return rc;
     HIP_TRY(hipMemcpyAsync(m->in_ids.p, ids_topk, (size_t)N * k * id_sz, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->in_q0.p, q0, (size_t)N * m->cfg.n0 * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->in_roa.p, res_of_atom, (size_t)N * 4, hipMemcpyHostToDevice, st));
@@ -386,17 +506,42 @@ int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_
             src = m->pack.data();
         }
         HIP_TRY(hipMemcpyAsync(m->in_X.p, src, (size_t)a.F * N * 3 * 4, hipMemcpyHostToDevice, st));
-        if (int rc = run_forward(m, st, a)) return rc;
-        HIP_TRY(hipMemcpyAsync(z_out + f0 * R * n_out, m->z.p, (size_t)a.F * R * n_out * 4, hipMemcpyDeviceToHost, st));
-        if (int rc = check_device_flag(m, st)) return rc;   // synchronises: staging buffers are free for the next chunk
+        float* dst = z_out + f0 * R * n_out;
+        const size_t zbytes = (size_t)a.F * R * n_out * 4;
+        auto copy_back = [&]() -> int { HIP_TRY(hipMemcpyAsync(dst, m->z.p, zbytes, hipMemcpyDeviceToHost, st)); return 0; };
+        if (int rc = forward_policy(m, st, a, true, copy_back)) return rc;   // synchronises: staging buffers are free for the next chunk
     }
     return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k, const float* X, const void* ids_topk, int32_t ids_kind,
+                  const float* q0, const int32_t* res_of_atom, float* z_out, int32_t ptr_kind, void* stream) {
+    return forward_common(m, N, R, k, 1, X, 3 * N, 3, ids_topk, ids_kind, q0, res_of_atom, z_out, 1, ptr_kind, stream, 0, nullptr);
+}
+
+int pesto_forward_structures(pesto_model* m, int64_t N, int64_t R, int32_t k, int32_t n_struct, const int32_t* struct_offsets, const float* X,
+                             const void* ids_topk, int32_t ids_kind, const float* q0, const int32_t* res_of_atom, float* z_out,
+                             int32_t ptr_kind, void* stream) {
+    if (n_struct < 1 || !struct_offsets) return fail(PESTO_ERR_INVALID, "n_struct must be >= 1 and struct_offsets non-null");
+    return forward_common(m, N, R, k, 1, X, 3 * N, 3, ids_topk, ids_kind, q0, res_of_atom, z_out, 1, ptr_kind, stream, n_struct, struct_offsets);
+}
+
+int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_frames, const float* X, int64_t x_frame_stride,
+                         int64_t x_atom_stride, const void* ids_topk, int32_t ids_kind, const float* q0, const int32_t* res_of_atom,
+                         float* z_out, int32_t frames_per_launch, int32_t ptr_kind, void* stream) {
+    return forward_common(m, N, R, k, n_frames, X, x_frame_stride, x_atom_stride, ids_topk, ids_kind, q0, res_of_atom, z_out,
+                          frames_per_launch, ptr_kind, stream, 0, nullptr);
 }
 
 int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, const int64_t* R, const int32_t* k, const float* const* X,
                         const void* const* ids_topk0, int32_t ids_kind, const float* const* q0, const int32_t* const* res_of_atom,
-                        float* const* z_out, void* stream) {
+                        float* const* z_out, int32_t batch_mode, void* stream) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (batch_mode != PESTO_BATCH_COLLATED && batch_mode != PESTO_BATCH_INDEPENDENT)
+        return fail(PESTO_ERR_INVALID, "batch_mode must be PESTO_BATCH_COLLATED or PESTO_BATCH_INDEPENDENT");
     if (n_struct < 1 || !N || !R || !k || !X || !ids_topk0 || !q0 || !res_of_atom || !z_out) return fail(PESTO_ERR_INVALID, "bad arguments");
     if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
     struct Meta { int off, roff, n, r, k; long long idoff; };
@@ -415,9 +560,11 @@ int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, cons
     const int n0 = m->cfg.n0, n_out = m->cfg.n_out;
     if (m->in_X.ensure((size_t)NT * 12) || m->in_ids.ensure((size_t)IT * id_sz) || m->in_q0.ensure((size_t)NT * n0 * 4) ||
         m->in_roa.ensure((size_t)NT * 4) || m->col_meta.ensure(meta.size() * sizeof(Meta)) || m->col_ids.ensure((size_t)NT * KMAX * 4) ||
-        m->col_roa.ensure((size_t)NT * 4))
+        m->col_roa.ensure((size_t)NT * 4) || m->col_seg.ensure((size_t)NT * 4) || m->col_segend.ensure((size_t)n_struct * 4))
         return fail(PESTO_ERR_NOMEM, "staging allocation failed");
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    Sequence seq(m, st);
+    if (seq.rc) return seq.rc;
     HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
     HIP_TRY(hipMemcpyAsync(m->col_meta.p, meta.data(), meta.size() * sizeof(Meta), hipMemcpyHostToDevice, st));
     for (int b = 0; b < n_struct; ++b) {       // per-structure arrays land back to back: the concatenations of dataset.py:93-94
@@ -428,16 +575,19 @@ int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, cons
         HIP_TRY(hipMemcpyAsync(m->in_roa.as<int>() + mb.off, res_of_atom[b], (size_t)mb.n * 4, hipMemcpyHostToDevice, st));
     }
     launch_collate(st, (int)NT, n_struct, m->col_meta.p, m->in_ids.p, ids_kind, m->in_roa.as<int>(), m->col_ids.as<int>(), m->col_roa.as<int>(),
-                   err_ptr(m));
+                   m->col_seg.as<int>(), m->col_segend.as<int>(), err_ptr(m));
     HIP_TRY(hipGetLastError());
     if (int rc = check_device_flag(m, st)) return rc;      // bad ids / residue columns are reported before the forward runs
     FwdArgs a;
     a.N = NT; a.R = RT; a.F = 1; a.k = KMAX; a.X = m->in_X.as<float>(); a.xs_frame = 3 * NT; a.xs_atom = 3;
     a.ids = m->col_ids.p; a.ids_kind = PESTO_IDS_INT32; a.q0 = m->in_q0.as<float>(); a.roa = m->col_roa.as<int>(); a.z_out = m->z.as<float>();
-    if (int rc = run_forward(m, st, a)) return rc;
-    for (int b = 0; b < n_struct; ++b)
-        HIP_TRY(hipMemcpyAsync(z_out[b], m->z.as<float>() + (size_t)meta[b].roff * n_out, (size_t)meta[b].r * n_out * 4, hipMemcpyDeviceToHost, st));
-    return check_device_flag(m, st);   // synchronises
+    if (batch_mode == PESTO_BATCH_INDEPENDENT) { a.n_seg = n_struct; a.seg_of_atom = m->col_seg.as<int>(); a.seg_end = m->col_segend.as<int>(); }
+    auto copy_back = [&]() -> int {
+        for (int b = 0; b < n_struct; ++b)
+            HIP_TRY(hipMemcpyAsync(z_out[b], m->z.as<float>() + (size_t)meta[b].roff * n_out, (size_t)meta[b].r * n_out * 4, hipMemcpyDeviceToHost, st));
+        return 0;
+    };
+    return forward_policy(m, st, a, true, copy_back);   // synchronises
 }
 
 int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
@@ -455,7 +605,7 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
     // the cell arrays. The slot table travels behind the offsets in the same device buffer.
     std::vector<int> host_tab((size_t)2 * n_struct + 1);
     int n_slots = 0;
-    const bool brute = getenv("PESTO_KNN_BRUTE") != nullptr;
+    const bool brute = m->knn_brute;
     for (int s = 0; s <= n_struct; ++s) host_tab[s] = struct_offsets[s];
     for (int s = 0; s < n_struct; ++s)
         host_tab[n_struct + 1 + s] = (!brute && struct_offsets[s + 1] - struct_offsets[s] >= knn_cell_min()) ? n_slots++ : -1;
@@ -474,6 +624,8 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
     };
     if (ptr_kind == PESTO_PTR_DEVICE) {
         hipStream_t st = (hipStream_t)stream;
+        Sequence seq(m, st);
+        if (seq.rc) return seq.rc;
         HIP_TRY(hipMemcpyAsync(m->knn_off.p, host_tab.data(), host_tab.size() * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));     // host_tab is a local: finish the copy before returning
         knn_launch(st, X, ids_out);
@@ -483,6 +635,8 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
     if (ptr_kind != PESTO_PTR_HOST) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     if (m->in_X.ensure((size_t)n_total * 12) || m->in_ids.ensure((size_t)n_total * KMAX * id_sz)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    Sequence seq(m, st);
+    if (seq.rc) return seq.rc;
     HIP_TRY(hipMemcpyAsync(m->knn_off.p, host_tab.data(), host_tab.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->in_X.p, X, (size_t)n_total * 12, hipMemcpyHostToDevice, st));
     knn_launch(st, m->in_X.as<float>(), m->in_ids.p);
@@ -501,6 +655,8 @@ int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, cons
     if (m->flags.ensure(64)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
     if (ptr_kind == PESTO_PTR_DEVICE) {
         // no flag reset / read-back here: the call stays asynchronous; a bad res_of_atom entry is clamped to residue 0
+        Sequence seq(m, (hipStream_t)stream);
+        if (seq.rc) return seq.rc;
         launch_postprocess((hipStream_t)stream, (int)N, (int)R, n_out, z, res_of_atom, p_out, bfactor_out, err_ptr(m));
         HIP_TRY(hipGetLastError());
         return 0;
@@ -512,6 +668,8 @@ int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, cons
         return fail(PESTO_ERR_NOMEM, "staging allocation failed");
     float* dp = out.as<float>();
     float* db = dp + (size_t)R * n_out;
+    Sequence seq(m, st);
+    if (seq.rc) { out.release(); return seq.rc; }
     int rc = 0;
     do {
         hipError_t he = hipMemsetAsync(m->flags.p, 0, 8, st);
@@ -537,6 +695,8 @@ int pesto_stage_embed(pesto_model* m, int64_t N, const float* q0, float* q_out) 
     if (int rc = ensure_workspace(m, N, 1)) return rc;
     if (m->in_q0.ensure((size_t)N * m->cfg.n0 * 4)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
     hipStream_t st = m->stream;
+    Sequence seq(m, st);
+    if (seq.rc) return seq.rc;
     HIP_TRY(hipMemcpyAsync(m->in_q0.p, q0, (size_t)N * m->cfg.n0 * 4, hipMemcpyHostToDevice, st));
     launch_embed(st, m->W, m->img.model.em, (int)N, (int)N, m->cfg.n0, m->in_q0.as<float>(), m->q_a.as<float>());
     HIP_TRY(hipMemcpyAsync(q_out, m->q_a.as<float>() + S, (size_t)N * S * 4, hipMemcpyDeviceToHost, st));
@@ -556,6 +716,8 @@ int pesto_stage_unpack(pesto_model* m, int64_t N, int32_t k, const float* X, con
     if (m->in_X.ensure((size_t)N * 3 * 4) || m->in_ids.ensure((size_t)N * k * id_sz)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
     hipStream_t st = m->stream;
     if (m->dmax.ensure(4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    Sequence seq(m, st);
+    if (seq.rc) return seq.rc;
     HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
     HIP_TRY(hipMemsetAsync(m->dmax.p, 0, 4, st));
     HIP_TRY(hipMemcpyAsync(m->in_X.p, X, (size_t)N * 3 * 4, hipMemcpyHostToDevice, st));
@@ -584,14 +746,18 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
     HIP_TRY(hipSetDevice(m->device));
     const size_t N1 = (size_t)m->stage_N + 1;
     hipStream_t st = m->stream;
+    Sequence seq(m, st);
+    if (seq.rc) return seq.rc;
+    HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
     HIP_TRY(hipMemcpyAsync(m->q_a.p, q_io, N1 * S * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->p_a.p, p_io, N1 * 96 * 4, hipMemcpyHostToDevice, st));
     const void *q_res = m->q_b.p, *p_res = m->p_b.p;
     if (m->impl == 2) {
         const LayerW* L = &m->img.layers[layer];
-        launch_node(st, m->W, nullptr, L, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->edge_variant);
-        launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->edge_blocks, m->edge_variant);
-        launch_node(st, m->W, L, nullptr, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->edge_variant);
+        const int ev = m->precision == PESTO_PRECISION_FP32 ? 1 : m->fast_variant;     // no automatic re-run at stage level
+        launch_node(st, m->W, nullptr, L, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), ev, err_ptr(m));
+        launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->edge_blocks, ev, err_ptr(m));
+        launch_node(st, m->W, L, nullptr, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), ev, err_ptr(m));
         q_res = m->q_a.p; p_res = m->p_a.p;
     } else {
         launch_layer_v1(st, m->W, m->img.layers[layer], (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->q_a.as<float>(), m->p_a.as<float>(),
@@ -600,8 +766,7 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(q_io, q_res, N1 * S * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(p_io, p_res, N1 * 96 * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return 0;
+    return check_device_flag(m, st);      // synchronises; reports a range overflow of the f16-split kernels (PESTO_ERR_RANGE)
 }
 
 int pesto_stage_pool(pesto_model* m, int64_t N, int64_t R, const float* q, const float* p, const int32_t* res_of_atom,
@@ -614,6 +779,8 @@ int pesto_stage_pool(pesto_model* m, int64_t N, int64_t R, const float* q, const
     DevBuf qr, pr;
     if (qr.ensure((size_t)R * S * 4) || pr.ensure((size_t)R * 96 * 4)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
     hipStream_t st = m->stream;
+    Sequence seq(m, st);
+    if (seq.rc) { qr.release(); pr.release(); return seq.rc; }
     int rc = 0;
     do {
         hipError_t he = hipMemsetAsync(m->flags.p, 0, 8, st);

@@ -9,17 +9,20 @@ namespace pesto {
 // N atoms in the batch; q0 has nq rows used with period nq (nq = N, or the frame length of a trajectory batch)
 void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state);
 // F coordinate frames of Nf atoms sharing one ids table [Nf,k] (F = 1: a plain collated batch); X strides in floats;
-// dmax_bits[F] must be zeroed
+// dmax_bits[F] must be zeroed. seg_of_atom / seg_end (F = 1 only, may be null): ragged structures that must behave like separate
+// calls - per-structure wrap-around target and max(D); dmax_bits then holds one zeroed word per structure
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
-                   int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag);
+                   int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag, const int* seg_of_atom = nullptr,
+                   const int* seg_end = nullptr);
 void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int* roa_f, int* err_flag);
 void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                      const float* q_in, const float* p_in, float* q_out, float* p_out);
-// MFMA layer (pesto_layer_mfma.hip): per-atom node kernel (finish previous layer / prepare records) + edge kernel
+// MFMA layer (pesto_layer_mfma.hip): per-atom node kernel (finish previous layer / prepare records) + edge kernel.
+// flags: the error word; the f16-split kernels set bit 4 when an activation left the f16 range (sat_probe)
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
-                 const float* Z, float* rec_nb, float* rec_cen, int variant);
+                 const float* Z, float* rec_nb, float* rec_cen, int variant, int* flags);
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
-                 const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant);
+                 const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags);
 // k-NN + collate; with use_grid the structures of at least knn_cell_min() atoms are searched through a uniform cell grid
 // (buffers: slots n_struct ints = block of the cell arrays per structure or -1, grids n_struct * knn_grid_struct_bytes(), cell_cnt /
 // cell_cur n_slots * knn_cells_per_struct() ints, cell_of n_total ints, sorted n_total float4), smaller ones by brute force; identical
@@ -30,8 +33,10 @@ size_t knn_grid_struct_bytes();
 int knn_cell_min();
 int knn_cells_per_struct();
 // meta: device array of {int off, roff, n, r, k; long long idoff} per structure (32 bytes each, see k_collate)
+// seg_of_atom [n_total] / seg_end [n_struct]: structure index of every atom and the end offset of every structure (for launch_unpack)
 void launch_collate(hipStream_t st, int n_total, int n_struct, const void* meta, const void* ids_raw, int ids_kind, const int* roa_raw,
-                    int* ids_out, int* roa_out, int* err_flag);
+                    int* ids_out, int* roa_out, int* seg_of_atom, int* seg_end, int* err_flag);
+void launch_segments(hipStream_t st, int n_total, int n_struct, const int* seg_end, int* seg_of_atom);
 void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z, const int* roa, float* p_out, float* bf_out, int* err_flag);
 void debug_print_phase_cycles();   // no-op unless built with -DPESTO_PROFILE_PHASES
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,

@@ -53,14 +53,41 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW
 // Frames (blockIdx.y): F independent coordinate sets of Nf atoms sharing ONE ids table (the MD use of the reference,
 // md_analysis/apply_model_md.ipynb cell 6: model(X_frame, ids_topk_of_frame0, q, M) per frame). Frame f becomes atoms
 // f*Nf+1 .. (f+1)*Nf of the internal batch; the wrap target and the max are per frame, exactly as in F separate calls.
+// Segments (seg_of_atom != nullptr, F = 1): a ragged batch whose structures must behave like separate calls (the reference's
+// bulk loops run one structure per call, apply_model.ipynb:139-167): atom i belongs to structure seg_of_atom[i] whose atoms
+// are [seg_end[s-1], seg_end[s]); padding wraps to the structure's own last atom and the max is per structure.
 template <typename IdT>
 __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __restrict__ X, int64_t xs_frame, int64_t xs_atom,
                                                  const IdT* __restrict__ ids, int* __restrict__ ids_s, float4* __restrict__ geo,
-                                                 unsigned* __restrict__ dmax_bits, int* __restrict__ err_flag) {
+                                                 unsigned* __restrict__ dmax_bits, int* __restrict__ err_flag,
+                                                 const int* __restrict__ seg_of_atom, const int* __restrict__ seg_end) {
     float d = 0.0f;
     const int f = blockIdx.y;
     const float* Xf = X + (int64_t)f * xs_frame;
     const int64_t a0 = (int64_t)f * Nf;
+    if (seg_of_atom) {   // ragged structures: one thread per slot, one integer atomic per wave and structure touched
+        const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (e >= (int64_t)Nf * KMAX) return;
+        const int i = (int)(e >> 6), c = (int)(e & 63);
+        const int sg = seg_of_atom[i];
+        long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
+        if (id < 0 || id > Nf) { atomicOr(err_flag, 1); id = 0; }
+        const long long j = id > 0 ? id - 1 : (long long)seg_end[sg] - 1;
+        const float* xj = Xf + j * xs_atom;
+        const float* xi = Xf + (int64_t)i * xs_atom;
+        const float rx = xj[0] - xi[0], ry = xj[1] - xi[1], rz = xj[2] - xi[2];
+        const float dd = sqrtf(rx * rx + ry * ry + rz * rz);
+        ids_s[(size_t)(i + 1) * KMAX + c] = (int)id;
+        geo[(size_t)(i + 1) * KMAX + c] = make_float4(rx, ry, rz, dd);
+        d = dd;
+        for (int off = 32; off > 0; off >>= 1) d = fmaxf(d, __shfl_xor(d, off));   // a wave = the 64 slots of ONE atom
+        // the maximum only grows: a wave whose value does not beat what is already published (L2-served read) skips the atomic,
+        // so a structure costs a few hundred atomics on its word instead of one per atom
+        if ((threadIdx.x & 63) == 0 && d > 0.0f &&
+            __float_as_uint(d) > __hip_atomic_load(dmax_bits + sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(dmax_bits + sg, __float_as_uint(d));
+        return;
+    }
     // 4 slots per thread (grid-stride by the grid size) keeps the number of blocks, hence atomics, at a quarter
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)Nf * KMAX; e += (int64_t)gridDim.x * 256) {
         const int i = (int)(e >> 6), c = (int)(e & 63);
@@ -90,11 +117,11 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
 
 // pass 2: D += max(D) * (D < 1e-2);  R /= D.  Also writes the sink row 0.   src/model_operations.py:12-20
 __global__ __launch_bounds__(256) void k_unpack2(int N, int Nf, int* __restrict__ ids_s, float4* __restrict__ geo,
-                                                 const unsigned* __restrict__ dmax_bits) {
+                                                 const unsigned* __restrict__ dmax_bits, const int* __restrict__ seg_of_atom) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over (N+1) * 64 slots
     if (e >= (int64_t)(N + 1) * KMAX) return;
     if (e < KMAX) { ids_s[e] = 0; geo[e] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
-    const float dmax = __uint_as_float(dmax_bits[((e >> 6) - 1) / Nf]);
+    const float dmax = __uint_as_float(dmax_bits[seg_of_atom ? seg_of_atom[(e >> 6) - 1] : ((e >> 6) - 1) / Nf]);
     float4 g = geo[e];
     const float d = g.w + dmax * (g.w < 1e-2f ? 1.0f : 0.0f);
     geo[e] = make_float4(g.x / d, g.y / d, g.z / d, d);
@@ -420,7 +447,7 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
                                                     const float* __restrict__ a, const int* __restrict__ roa,
                                                     const int* __restrict__ lo, const int* __restrict__ hi,
                                                     float* __restrict__ qr_out, float* __restrict__ pr_out,
-                                                    float* __restrict__ z_out) {
+                                                    float* __restrict__ z_out, const int* __restrict__ flags) {
     __shared__ float qh[128];
     __shared__ float ph[3][128];
     __shared__ float hs[64];
@@ -428,7 +455,9 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
     const int r = blockIdx.x;
     const int lane = threadIdx.x, s = lane & 31, hf = lane >> 5;
     const int i0 = lo[r], i1 = hi[r];
-    if (i0 >= i1) {   // empty residue: the reference degenerates to a whole-batch softmax; flagged with NaN here
+    // bad ids / residue columns, or an activation beyond the f16 range on the split-MFMA path (flag bit 4): the result would be
+    // silently wrong (ELU maps the NaN of an overflowed product to 0), so it is made loud - every logit NaN
+    if (i0 >= i1 || (*flags & 7)) {   // (empty residue: the reference degenerates to a whole-batch softmax; NaN here)
         if (lane < n_out) z_out[(size_t)r * n_out + lane] = __uint_as_float(0x7fc00000u);
         return;
     }
@@ -507,16 +536,17 @@ void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq,
 }
 
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
-                   int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag) {
+                   int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag, const int* seg_of_atom, const int* seg_end) {
     const int64_t n1 = (int64_t)Nf * KMAX, nall = (int64_t)Nf * F * KMAX;
-    const dim3 grid1((unsigned)((n1 + 1023) / 1024), (unsigned)F), grid2((unsigned)((nall + KMAX + 255) / 256));
+    const dim3 grid1((unsigned)((n1 + (seg_of_atom ? 255 : 1023)) / (seg_of_atom ? 256 : 1024)), (unsigned)F),
+        grid2((unsigned)((nall + KMAX + 255) / 256));
     if (ids_kind == PESTO_IDS_INT64)
         hipLaunchKernelGGL(k_unpack1<long long>, grid1, dim3(256), 0, st, Nf, k, X, xs_frame, xs_atom, (const long long*)ids, ids_s, geo,
-                           dmax_bits, err_flag);
+                           dmax_bits, err_flag, seg_of_atom, seg_end);
     else
         hipLaunchKernelGGL(k_unpack1<int>, grid1, dim3(256), 0, st, Nf, k, X, xs_frame, xs_atom, (const int*)ids, ids_s, geo, dmax_bits,
-                           err_flag);
-    hipLaunchKernelGGL(k_unpack2, grid2, dim3(256), 0, st, Nf * F, Nf, ids_s, geo, dmax_bits);
+                           err_flag, seg_of_atom, seg_end);
+    hipLaunchKernelGGL(k_unpack2, grid2, dim3(256), 0, st, Nf * F, Nf, ids_s, geo, dmax_bits, seg_of_atom);
 }
 
 void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int* roa_f, int* err_flag) {
@@ -528,7 +558,7 @@ void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, in
     hipLaunchKernelGGL(k_seg_init, dim3((R + 255) / 256), dim3(256), 0, st, R, lo, hi);
     hipLaunchKernelGGL(k_seg_bounds, dim3((N + 255) / 256), dim3(256), 0, st, N, R, roa, lo, hi, err_flag);
     hipLaunchKernelGGL(k_pool_logits, dim3((N + 7) / 8), dim3(256), 0, st, W, mw.sam, N, q, p, a_tmp);
-    hipLaunchKernelGGL(k_pool_reduce, dim3(R), dim3(64), 0, st, W, mw, n_out, R, q, p, a_tmp, roa, lo, hi, qr_out, pr_out, z_out);
+    hipLaunchKernelGGL(k_pool_reduce, dim3(R), dim3(64), 0, st, W, mw, n_out, R, q, p, a_tmp, roa, lo, hi, qr_out, pr_out, z_out, err_flag);
 }
 
 
@@ -763,8 +793,9 @@ struct CollateMeta { int off, roff, n, r, k; long long idoff; };
 template <typename IdT>
 __global__ __launch_bounds__(256) void k_collate(int n_total, int n_struct, const CollateMeta* __restrict__ meta, const IdT* __restrict__ ids_raw,
                                                  const int* __restrict__ roa_raw, int* __restrict__ ids_out, int* __restrict__ roa_out,
-                                                 int* __restrict__ err_flag) {
+                                                 int* __restrict__ seg_of_atom, int* __restrict__ seg_end, int* __restrict__ err_flag) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n_struct) seg_end[e] = meta[e].off + meta[e].n;
     if (e >= (int64_t)n_total * KMAX) return;
     const int i = (int)(e >> 6), c = (int)(e & 63);
     int lo = 0, hi = n_struct;
@@ -780,18 +811,31 @@ __global__ __launch_bounds__(256) void k_collate(int n_total, int n_struct, cons
         int r = roa_raw[i];
         if (r < 0 || r >= mb.r) { atomicOr(err_flag, 2); r = 0; }
         roa_out[i] = r + mb.roff;
+        seg_of_atom[i] = lo;
     }
 }
 
+// seg_of_atom[i] = index of the structure whose range [seg_end[s-1], seg_end[s]) holds atom i
+__global__ __launch_bounds__(256) void k_segments(int n_total, int n_struct, const int* __restrict__ seg_end, int* __restrict__ seg_of_atom) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    int lo = 0, hi = n_struct - 1;          // first s with seg_end[s] > i
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (seg_end[mid] > i) hi = mid; else lo = mid + 1; }
+    seg_of_atom[i] = lo;
+}
+void launch_segments(hipStream_t st, int n_total, int n_struct, const int* seg_end, int* seg_of_atom) {
+    hipLaunchKernelGGL(k_segments, dim3((n_total + 255) / 256), dim3(256), 0, st, n_total, n_struct, seg_end, seg_of_atom);
+}
+
 void launch_collate(hipStream_t st, int n_total, int n_struct, const void* meta, const void* ids_raw, int ids_kind, const int* roa_raw,
-                    int* ids_out, int* roa_out, int* err_flag) {
+                    int* ids_out, int* roa_out, int* seg_of_atom, int* seg_end, int* err_flag) {
     const dim3 grid((unsigned)(((int64_t)n_total * KMAX + 255) / 256)), block(256);
     if (ids_kind == PESTO_IDS_INT64)
         hipLaunchKernelGGL(k_collate<long long>, grid, block, 0, st, n_total, n_struct, (const CollateMeta*)meta, (const long long*)ids_raw, roa_raw,
-                           ids_out, roa_out, err_flag);
+                           ids_out, roa_out, seg_of_atom, seg_end, err_flag);
     else
         hipLaunchKernelGGL(k_collate<int>, grid, block, 0, st, n_total, n_struct, (const CollateMeta*)meta, (const int*)ids_raw, roa_raw, ids_out,
-                           roa_out, err_flag);
+                           roa_out, seg_of_atom, seg_end, err_flag);
 }
 
 // ------------------------------------------------------------------------------------------------ post-processing

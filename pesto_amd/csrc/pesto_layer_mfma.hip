@@ -57,6 +57,17 @@ __device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
         lo[j] = l[0]; lo[j + 1] = l[1];
     }
 }
+// Range guard of the f16-split path. A value beyond +-65504 splits into hi = +-inf, lo = -+inf, and every MFMA output fed by
+// it becomes NaN (inf - inf, or 0 * inf). ELU = med3(x, exp(x) - 1, 0) turns that NaN into 0, i.e. into a silently wrong
+// result, so one register of every accumulator chain is probed BEFORE its ELU: x * 0 + acc stays 0 for finite x and
+// becomes NaN for inf / NaN (one v_fmac_f32). Chains that reach Z or the state without an ELU (keys -> softmax weights,
+// values -> weighted sums, qpm / ppm outputs) carry their NaN to the next node kernel's probes. A wave whose probe ended
+// as NaN sets bit 4 of the flags word; the host re-runs the forward on the exact fp32 kernels (PESTO_PRECISION_AUTO) or
+// reports the range error, and the pool kernel turns every logit into NaN - never a plausible wrong number.
+__device__ __forceinline__ void sat_probe(float& acc, float x) { acc = __builtin_fmaf(x, 0.0f, acc); }
+__device__ __forceinline__ void sat_flush(float acc, int* __restrict__ flags) {
+    if (acc != acc) atomicOr(flags, 4);
+}
 __device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast<const f16x8*>(p); }
 #ifdef PESTO_ABL_NOWL   // ablation: the low weight fragments are not read from LDS (results wrong): -1/3 of the LDS weight traffic
 #define PESTO_WL(fr) ld8h(fr) 
@@ -313,8 +324,10 @@ template <bool HY> constexpr int node_lds_floats() { return nl_nq<HY>() + 3584; 
 template <bool HY>
 __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
                                                 int N1, float* __restrict__ q_state, float* __restrict__ p_state,
-                                                const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen) {
+                                                const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen,
+                                                int* __restrict__ flags) {
     const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
+    float sat = 0.0f;
     // wave-uniform by construction; readfirstlane makes it uniform for the compiler too (scalar branches around the MFMA blocks)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), role = wave & 3, slot = wave >> 2;
     __shared__ __attribute__((aligned(16))) float wl_[node_lds_floats<HY>()];
@@ -362,10 +375,12 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
                     split8(ld4(zr + 32 * kgp + 4 * g), ld4(zr + 32 * kgp + 16 + 4 * g), xh, xl);
                     mfma16_multi<2>(Lq0, 0, 2, kgp, lane, xh, xl, h);
                 }
+                sat_probe(sat, h[0][0]);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) { h[m] = elu4(h[m]); t[m] = ld4(W + wf_.n_bq1 + 16 * m + 4 * g); }
                 split8(h[0], h[1], xh, xl);
                 mfma16_multi<2>(Lq1, 0, 1, 0, lane, xh, xl, t);
+                sat_probe(sat, t[0][0]);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) { t[m] = elu4(t[m]); h[m] = ld4(W + wf_.n_bq2 + 16 * m + 4 * g); }
                 split8(t[0], t[1], xh, xl);
@@ -383,6 +398,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
 #pragma unroll
                 for (int m = 0; m < 2; ++m) st[m] += a[m];
             }
+            sat_probe(sat, st[0][0]);
             if (i == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
             if (valid) {
                 float* dst = role == 0 ? q_state + (size_t)i * S : p_state + (size_t)i * 96 + (role - 1) * 32;
@@ -425,6 +441,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
             for (int j = 0; j < 4; ++j) a[j] = ob < 8 ? ld4(W + wp_.n_b1 + 16 * (ob + j) + 4 * g) : f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<4>(Lua, ob, 2, kgp, lane, xnh[kgp], xnl[kgp], a);
+            sat_probe(sat, a[0][0]);
             if (valid) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -451,6 +468,8 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
             for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wh[0], pl[c], a[0][c]); a[1][c] = MFMA16(wh[1], pl[c], a[1][c]); }
 #pragma unroll
             for (int c = 0; c < 3; ++c) { a[0][c] = MFMA16(wl[0], ph[c], a[0][c]); a[1][c] = MFMA16(wl[1], ph[c], a[1][c]); }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sat_probe(sat, a[0][c][0]);
             if (valid) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -467,14 +486,18 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
             for (int m = 0; m < 2; ++m) { h[m] = ld4(W + wp_.n_bn0 + 16 * m + 4 * g); t[m] = ld4(W + wp_.n_bn1 + 16 * m + 4 * g); }
 #pragma unroll
             for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<2>(Lnq, 0, 2, kgp, lane, xnh[kgp], xnl[kgp], h);
+            sat_probe(sat, h[0][0]);
             split8(elu4(h[0]), elu4(h[1]), xh, xl);
             mfma16_multi<2>(Lnq + 2048, 0, 1, 0, lane, xh, xl, t);
+            sat_probe(sat, t[0][0]);
             f32x4 qq[1] = {ld4(W + wp_.n_bn2 + 4 * g)};
             split8(elu4(t[0]), elu4(t[1]), xh, xl);
             mfma16_multi<1>(Lnq + 3072, 0, 1, 0, lane, xh, xl, qq);
+            sat_probe(sat, qq[0][0]);
             if (valid) st4(cen + 512 + 4 * g, qq[0]);
         }
     }
+    sat_flush(sat, flags);
 }
 
 // ---- cross-lane reductions on the VALU (DPP) instead of ds_bpermute round trips through the LDS crossbar
@@ -648,7 +671,7 @@ __device__ __forceinline__ L1Head l1_head(const L1Raw& r, int t, int lane, const
 }
 
 __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, const float* __restrict__ w1p, const float* __restrict__ wd,
-                                        f32x4* h1) {
+                                        f32x4* h1, float& sat) {
 #pragma unroll
     for (int m0 = 0; m0 < 4; m0 += 2) {
         f16x8 wh[2], wl[2];
@@ -664,6 +687,7 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) o.acc[m0 + ml] = MFMA16(wl[ml], o.fh, o.acc[m0 + ml]);
     }
+    sat_probe(sat, o.acc[0][0]);      // p_j . r_hat beyond the f16 range
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
         const f32x4 w4 = ld4(wd + 16 * (fb0 + fb) + 4 * g);
@@ -691,7 +715,7 @@ template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
-                                                 const float* __restrict__ p_state, float* __restrict__ Z) {
+                                                 const float* __restrict__ p_state, float* __restrict__ Z, int* __restrict__ flags) {
     // TI = 16-edge tiles per wave work item: 4 (64 edge rows) for full launches; small launches (one structure) use finer
     // items - 1 tile for nn = 8 / 16, 2 for nn = 32 - so that the launch is spread over more waves and CUs (latency)
     constexpr int A = 16 * TI / NN;            // whole centres per work item
@@ -720,6 +744,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     const int chunk = (n_work + 7) >> 3;
     const int w_end = min(n_work, (xcd + 1) * chunk);
     PHASE_DECL();
+    float sat = 0.0f;       // range guard of the f16-split path (sat_probe)
     for (int work = xcd * chunk + jb * WPB + wave; work < w_end; work += nbx * WPB) {
         const int c0 = work * A;
         PHASE_INIT();
@@ -759,6 +784,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     for (int a = 0; a < 4; ++a) acc2[a] = MFMA16(wh[a], xl[a >> 1], acc2[a]);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) acc2[a] = MFMA16(wl[a], xh[a >> 1], acc2[a]);
+                    sat_probe(sat, acc2[0][0]);      // h1 of the scalar-key net (blocks 0, 1) beyond the f16 range
+                    sat_probe(sat, acc2[2][0]);      // ... of the vector-key net (blocks 2, 3)
                     // keys: K = 64 = k-group 0 (eq h2 blocks) + k-group 1 (ep h2 blocks); two accumulators, summed
                     f32x4 kacb = f32x4{0, 0, 0, 0};
                     f16x8 kh[2], kl[2];
@@ -855,7 +882,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         // wave priority: a wave inside its MFMA burst (first-layer tail, key / value networks) goes ahead of waves that are in
                         // VALU / LDS phases (softmax, weighted sums, finalize) - measured +3.8 % (levels 1..3 alike)
                         __builtin_amdgcn_s_setprio(1);
-                        l1_tail(hd, 0, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1);
+                        l1_tail(hd, 0, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
                         keys_of_tile(t, h1);
                         __builtin_amdgcn_s_setprio(0);
                     }
@@ -976,7 +1003,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 __builtin_amdgcn_sched_barrier(0);
                 L1Head hd = l1_head<NN>(raw, t, lane, tc, ws);
                 __builtin_amdgcn_s_setprio(1);
-                l1_tail(hd, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1);
+                l1_tail(hd, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
             } else {
                 l1_tile_lean<NN>(4, lane, g, tc, sm.w + EL_WD, h1);
             }
@@ -1021,6 +1048,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         for (int ml = 0; ml < G; ++ml) acc2[m0 + ml] = MFMA16(wl[ml], xh, acc2[m0 + ml]);
                     }
                 }
+                sat_probe(sat, acc2[0][0]);          // h1 of the value net beyond the f16 range
             } else {
 #pragma unroll
                 for (int fbl = 0; fbl < 4; ++fbl) mfma_multi<4, 4>(w2f + 8 * 256, 0, fbl, lane, h1[fbl], acc2);
@@ -1182,6 +1210,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             PHASE_MARK(6);
         }
     }
+    if (F16) sat_flush(sat, flags);
     PHASE_FLUSH();
 }
 
@@ -1199,7 +1228,7 @@ void debug_print_phase_cycles() {
 
 // =============================================================================================== launchers
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
-                 const float* Z, float* rec_nb, float* rec_cen, int variant) {
+                 const float* Z, float* rec_nb, float* rec_cen, int variant, int* flags) {
     const int tiles = (N1 + 15) / 16, chunk = (tiles + 7) / 8;
     const LayerW dummy{};
     const LayerW& wf = finish ? *finish : dummy;
@@ -1213,32 +1242,32 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
     const int pair_chunk = ((tiles + 1) / 2 + 7) / 8;
     const dim3 grid((pair_chunk < 32 ? pair_chunk : 32) * 8), block(NODE_WAVES * 64);
     if (variant == 0)
-        hipLaunchKernelGGL(k_node16<true>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
+        hipLaunchKernelGGL(k_node16<true>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags);
     else
-        hipLaunchKernelGGL(k_node16<false>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen);
+        hipLaunchKernelGGL(k_node16<false>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags);
 }
 
 template <int NN, int WPB, bool PF, bool F16, bool HY, int TI>
 static void launch_edge_k(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo, const float* rec_nb,
-                          const float* rec_cen, const float* p_state, float* Z, int max_blocks) {
+                          const float* rec_cen, const float* p_state, float* Z, int max_blocks, int* flags) {
     constexpr int A = 16 * TI / NN;
     const int n_work = (N1 + A - 1) / A;
     int blocks = ((n_work + 7) / 8 + WPB - 1) / WPB * 8;   // per-XCD share of the work items, WPB per workgroup, x 8 XCDs
     if (blocks > max_blocks) blocks = max_blocks / 8 * 8;
     if (blocks < 8) blocks = 8;
     hipLaunchKernelGGL((k_edge<NN, WPB, PF, F16, HY, TI>), dim3(blocks), dim3(WPB * 64), 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen,
-                       p_state, Z);
+                       p_state, Z, flags);
 }
 
 // FINE = false: 64-row work items for every nn; FINE = true: the finest work item that still holds whole centres
 template <int WPB, bool PF, bool F16, bool HY = false, bool FINE = false>
 static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
-                          const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks) {
+                          const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int* flags) {
     switch (lw.nn) {
-        case 8: launch_edge_k<8, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks); break;
-        case 16: launch_edge_k<16, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks); break;
-        case 32: launch_edge_k<32, WPB, PF, F16, HY, FINE ? 2 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks); break;
-        default: launch_edge_k<64, WPB, PF, F16, HY, 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks); break;
+        case 8: launch_edge_k<8, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags); break;
+        case 16: launch_edge_k<16, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags); break;
+        case 32: launch_edge_k<32, WPB, PF, F16, HY, FINE ? 2 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags); break;
+        default: launch_edge_k<64, WPB, PF, F16, HY, 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags); break;
     }
 }
 
@@ -1247,18 +1276,18 @@ static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int 
 // variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch), full 2 KB neighbour records
 // variant 5: the previous default - full neighbour records, register-lean VALU first layer, f16-split MFMA, 12 waves per workgroup
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
-                 const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant) {
+                 const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags) {
     // small launches (one structure, or the nn = 8/16 layers of a small batch) cannot fill 256 twelve-wave workgroups:
     // the same kernel body in smaller workgroups spreads them over more CUs
     const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
     if (variant == 1) {
-        launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+        launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags);
     } else if (variant == 5) {
-        if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
-        else launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks);
+        if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256, flags);
+        else launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags);
     } else {
-        if (n_work >= 2048) launch_edge_t<12, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);
-        else launch_edge_t<8, false, true, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256);   // 63 KB of constants: one
+        if (n_work >= 2048) launch_edge_t<12, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256, flags);
+        else launch_edge_t<8, false, true, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256, flags);   // 63 KB of constants: one
                                                                                                    // workgroup per CU; fine work items
     }
 }

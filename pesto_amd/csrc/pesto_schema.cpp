@@ -9,6 +9,7 @@ bool config_ok(const pesto_config* c) {
     if (!c || c->n0 < 1 || c->n0 > 512 || c->n_layers < 1 || c->n_layers > PESTO_MAX_LAYERS) return false;
     if (c->n_out < 1 || c->n_out > 32) return false;
     if ((c->em_depth != 1 && c->em_depth != 3) || (c->dm_depth != 1 && c->dm_depth != 3)) return false;
+    if (c->precision != PESTO_PRECISION_AUTO && c->precision != PESTO_PRECISION_F16_SPLIT && c->precision != PESTO_PRECISION_FP32) return false;
     for (int l = 0; l < c->n_layers; ++l)
         if (c->nn[l] != 8 && c->nn[l] != 16 && c->nn[l] != 32 && c->nn[l] != 64) return false;
     return true;

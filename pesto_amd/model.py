@@ -11,6 +11,10 @@ Drop-in usage, as in apply_model.ipynb:73-93,155:
 All arithmetic runs in libpesto_hip.so on the MI355X; there is no PyTorch or CPU fallback. ``device`` only
 says where the caller's tensors live: CUDA(ROCm) tensors are consumed in place on torch's current stream,
 CPU tensors / numpy arrays are staged through the library's own buffers.
+
+``precision`` (no reference counterpart - torch computes in fp32): "auto" (default) runs the state-update GEMMs as f16 hi/lo
+split MFMA and repeats a forward on the exact fp32 kernels when an activation left the f16 range; "f16_split" never
+repeats (such a forward raises / returns NaN); "fp32" always uses the exact fp32 MFMA kernels (enum pesto_precision).
 """
 import ctypes
 
@@ -27,9 +31,11 @@ def _is_torch(x):
 
 
 class Model:
-    def __init__(self, config, device=None, validate=True):
+    def __init__(self, config, device=None, validate=True, precision="auto"):
         self.config = normalise(config)
-        self._cc = _lib.make_c_config(self.config)
+        self.precision = str(precision).lower()
+        self._cc = _lib.make_c_config(self.config, self.precision)
+        self._debug = (0, 0)        # pesto_debug_select(layer_kernels, knn_brute_force): test hook
         self._blob = None
         self._handle = None
         self._gpu = 0
@@ -41,10 +47,36 @@ class Model:
 
     # ------------------------------------------------------------------ torch.nn.Module-like surface
     def load_state_dict(self, state_dict, strict=True):
-        """Accepts the reference's state_dict (torch tensors or numpy arrays). Strict like torch's."""
-        self._blob = np.ascontiguousarray(flatten_state_dict(self.config, state_dict), dtype=np.float32)
+        """Accepts the reference's state_dict (torch tensors or numpy arrays). ``strict=True`` (torch's default): missing AND
+        unexpected keys raise KeyError. ``strict=False`` ignores unexpected keys only - every parameter of the architecture must
+        still be present, because a handle cannot be built from a partial blob (torch would keep its random initialisation)."""
+        self._blob = np.ascontiguousarray(flatten_state_dict(self.config, state_dict, strict=strict), dtype=np.float32)
         self._release()
         return "<All keys matched successfully>"
+
+    def set_precision(self, precision):
+        """"auto" | "f16_split" | "fp32" (pesto_set_precision); takes effect with the next call."""
+        code = _lib.precision_code(precision)
+        self.precision = str(precision).lower()
+        self._cc.precision = code
+        if self._handle is not None:
+            _lib.check(_lib.load().pesto_set_precision(self._handle, code))
+        return self
+
+    def status(self):
+        """{"precision", "n_forward", "n_fp32_rerun"}: launch sequences run by this handle and how many "auto" repeated on the
+        exact fp32 kernels (pesto_get_status)."""
+        p, a, b = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.load().pesto_get_status(self._ensure(), ctypes.byref(p), ctypes.byref(a), ctypes.byref(b)))
+        return {"precision": {v: k for k, v in _lib.PRECISIONS.items()}[p.value], "n_forward": a.value, "n_fp32_rerun": b.value}
+
+    def debug_select(self, layer_kernels=0, knn_brute_force=False):
+        """Test hook (pesto_debug_select): 0 = shipped kernels, 1 = fp32 VALU reference-formulation kernel, 5 = f16-split with
+        full neighbour records; brute-force k-NN."""
+        self._debug = (int(layer_kernels), int(bool(knn_brute_force)))
+        if self._handle is not None:
+            _lib.check(_lib.load().pesto_debug_select(self._handle, *self._debug))
+        return self
 
     def state_dict(self):
         if self._blob is None:
@@ -109,6 +141,8 @@ class Model:
             _lib.check(lib.pesto_create(ctypes.byref(self._cc), self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size,
                                         self._gpu, ctypes.byref(h)))
             self._handle = h
+            if self._debug != (0, 0):
+                _lib.check(lib.pesto_debug_select(h, *self._debug))
         return self._handle
 
     @property
@@ -131,12 +165,26 @@ class Model:
 
     __call__ = forward
 
-    def forward_segments(self, X, ids_topk, q0, res_of_atom, R):
-        """Same as forward() with the residue mask given as res_of_atom [N] int32 (column index per atom)."""
+    def forward_segments(self, X, ids_topk, q0, res_of_atom, R, sizes=None):
+        """Same as forward() with the residue mask given as res_of_atom [N] int32 (column index per atom).
+        ``sizes``: atom counts of the structures the collated batch consists of - every structure then gets the result of its own
+        call (per-structure wrap-around target and max(D); pesto_forward_structures), as in the reference's bulk loops."""
         h = self._ensure()
         lib = _lib.load()
         n0 = self.config["em"]["N0"]
         n_out = self.config["dm"]["N2"]
+        offs = None
+        if sizes is not None:
+            offs = np.zeros(len(sizes) + 1, dtype=np.int32)
+            offs[1:] = np.cumsum([int(v) for v in sizes])
+            if int(offs[-1]) != int(X.shape[0]):
+                raise ValueError(f"sizes sum to {int(offs[-1])}, X has {int(X.shape[0])} atoms")
+
+        def call(N, k, xp, ip, kind, qp, rp, zp, ptr_kind, stream):
+            if offs is None:
+                return lib.pesto_forward(h, N, R, k, xp, ip, kind, qp, rp, zp, ptr_kind, stream)
+            return lib.pesto_forward_structures(h, N, R, k, len(offs) - 1, offs.ctypes.data, xp, ip, kind, qp, rp, zp, ptr_kind, stream)
+
         if _is_torch(X) and X.is_cuda:
             import torch
             if X.device.index != self._gpu:
@@ -153,9 +201,8 @@ class Model:
             self._check_shapes(N, Xc.shape, qc.shape, roa.shape, n0)
             z = torch.empty((R, n_out), dtype=torch.float32, device=X.device)
             stream = torch.cuda.current_stream(X.device).cuda_stream
-            _lib.check(lib.pesto_forward(h, N, R, k, Xc.data_ptr(), ids.data_ptr(),
-                                         _lib.IDS_INT64 if ids.dtype == torch.int64 else _lib.IDS_INT32,
-                                         qc.data_ptr(), roa.data_ptr(), z.data_ptr(), _lib.PTR_DEVICE, stream))
+            _lib.check(call(N, k, Xc.data_ptr(), ids.data_ptr(), _lib.IDS_INT64 if ids.dtype == torch.int64 else _lib.IDS_INT32,
+                            qc.data_ptr(), roa.data_ptr(), z.data_ptr(), _lib.PTR_DEVICE, stream))
             return z
         # host path: CPU torch tensors or numpy arrays
         as_torch = _is_torch(X)
@@ -170,8 +217,8 @@ class Model:
         self._check_shapes(N, Xn.shape, qn.shape, roa.shape, n0)
         z = np.empty((R, n_out), dtype=np.float32)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        _lib.check(lib.pesto_forward(h, N, R, k, p(Xn), p(idn), _lib.IDS_INT64 if idn.dtype == np.int64 else _lib.IDS_INT32,
-                                     p(qn), p(roa), p(z), _lib.PTR_HOST, None))
+        _lib.check(call(N, k, p(Xn), p(idn), _lib.IDS_INT64 if idn.dtype == np.int64 else _lib.IDS_INT32,
+                        p(qn), p(roa), p(z), _lib.PTR_HOST, None))
         if as_torch:
             import torch
             return torch.from_numpy(z)
@@ -187,10 +234,13 @@ class Model:
             raise ValueError(f"residue mask must cover N={N} atoms, got {tuple(rs)}")
 
     # ------------------------------------------------------------------ list of structures -> one launch (SURVEY 8b)
-    def forward_batch(self, structures):
+    def forward_batch(self, structures, independent=False):
         """[z_b] for structures = [(X, ids_topk0, q0, M), ...] exactly as the reference hands them to collate_batch_features
         (src/dataset.py:91-112; ids_topk0 0-based [N_b, min(64, N_b)] from extract_topology, M the structure's own [N_b, R_b]
-        mask): collated on the device and run as ONE batch. Host arrays (numpy / CPU tensors) in, numpy out."""
+        mask): collated on the device and run as ONE batch. Host arrays (numpy / CPU tensors) in, numpy out.
+        independent=False: the reference's forward on the collated batch (one max(D), padding wraps to the batch's last atom);
+        independent=True: every structure as in its own call, the semantics of the reference's bulk inference loops
+        (apply_model.ipynb:139-167) - results do not depend on the grouping (PESTO_BATCH_INDEPENDENT)."""
         h = self._ensure()
         lib = _lib.load()
         n0, n_out = self.config["em"]["N0"], self.config["dm"]["N2"]
@@ -222,7 +272,8 @@ class Model:
             zs.append(z)
             Np[b], Rp[b], kp[b] = N, R, idn.shape[1]
             Xp[b], Ip[b], Qp[b], Ap[b], Zp[b] = Xn.ctypes.data, idn.ctypes.data, qn.ctypes.data, roa.ctypes.data, z.ctypes.data
-        _lib.check(lib.pesto_forward_batch(h, nb, Np, Rp, kp, Xp, Ip, _lib.IDS_INT64 if kind == np.int64 else _lib.IDS_INT32, Qp, Ap, Zp, None))
+        _lib.check(lib.pesto_forward_batch(h, nb, Np, Rp, kp, Xp, Ip, _lib.IDS_INT64 if kind == np.int64 else _lib.IDS_INT32, Qp, Ap, Zp,
+                                           _lib.BATCH_INDEPENDENT if independent else _lib.BATCH_COLLATED, None))
         return zs
 
     # ------------------------------------------------------------------ trajectory frames

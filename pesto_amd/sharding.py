@@ -10,7 +10,11 @@ torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
     and one all_gather of padded payloads,
   * barriers / the max-over-ranks timing reduction of bench.py.
 """
+import logging
+
 import numpy as np
+
+log = logging.getLogger("pesto_amd.sharding")
 
 
 def partition(costs, world_size):
@@ -41,18 +45,29 @@ def batches(indices, sizes, max_atoms):
     return out
 
 
+def _skippable():
+    """Per-structure failures the bulk loop skips (the reference driver wraps each structure in try/except and continues,
+    interfaceome/apply_model.py:57-82): bad inputs reported by the library or the host checks. Anything else - a missing
+    library, a HIP failure, out of memory - is systemic and propagates."""
+    from ._lib import PestoError
+    return (PestoError, ValueError)
+
+
 def forward_local(forward_fn, structures, indices, max_atoms=32768):
     """Run ``forward_fn(X, ids_topk, q, M) -> z`` (or a pesto_amd.Model) over this rank's structures, collating several per launch.
     ``structures[i] = (X, ids_topk0, q, M)`` with the per-structure contract of pesto_amd.topology.
-    Returns {index: z_i (numpy [R_i, n_out])}.  A structure whose batch raises is retried alone and skipped on a
-    second failure (the reference driver also skips and continues)."""
+    Returns {index: z_i (numpy [R_i, n_out])}.  With a Model the launches use PESTO_BATCH_INDEPENDENT: every structure gets
+    the result of its own call whatever it was grouped with, so any partition over ranks gives the same bits.
+    A structure whose batch raises PestoError / ValueError is retried alone, logged and skipped (None) on a second failure;
+    if EVERY structure of this rank fails the last error is re-raised (a systemic problem, not a bad input)."""
     from .topology import collate_batch_features
     sizes = [np.asarray(s[0]).shape[0] for s in structures]
     results = {}
+    skippable = _skippable()
 
     def run(group):
         if hasattr(forward_fn, "forward_batch"):      # a pesto_amd.Model: collate on the device (pesto_forward_batch)
-            for i, z in zip(group, forward_fn.forward_batch([tuple(structures[i]) for i in group])):
+            for i, z in zip(group, forward_fn.forward_batch([tuple(structures[i]) for i in group], independent=True)):
                 results[i] = np.ascontiguousarray(z)
             return
         X, ids, q, M = collate_batch_features([list(structures[i]) for i in group])
@@ -64,23 +79,45 @@ def forward_local(forward_fn, structures, indices, max_atoms=32768):
             results[i] = np.ascontiguousarray(z[r0:r0 + r])
             r0 += r
 
+    last_error = None
     for group in batches(indices, sizes, max_atoms):
         try:
             run(group)
-        except Exception:
+        except skippable as e_group:
+            if len(group) == 1:
+                log.warning("structure %d skipped: %s", group[0], e_group)
+                results[group[0]] = None
+                last_error = e_group
+                continue
             for i in group:
                 try:
                     run([i])
-                except Exception:
+                except skippable as e:
+                    log.warning("structure %d skipped: %s", i, e)
                     results[i] = None
+                    last_error = e
+    if indices and last_error is not None and all(results.get(i) is None for i in indices):
+        raise last_error
     return results
 
 
-def gather_results(local, n_total, n_out, group=None, device="cpu"):
-    """All ranks receive every structure's z. ``local``: {index: array or None}. Two collectives:
-    all_gather of (index, rows) descriptors, all_gather of row payloads padded to the largest rank."""
+def _collective_device(group=None):
+    """Tensors of a collective must live where the backend works: RCCL ("nccl") needs device tensors, gloo host tensors."""
     import torch
     import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_results(local, n_total, n_out, group=None, device=None):
+    """All ranks receive every structure's z. ``local``: {index: array or None}. Three small collectives:
+    all_gather of (index, rows) descriptors and row counts, all_gather of row payloads padded to the largest rank.
+    ``device``: where the collective tensors live; default from the group's backend (cuda for nccl = RCCL, cpu for gloo)."""
+    import torch
+    import torch.distributed as dist
+    if device is None:
+        device = _collective_device(group)
     world = dist.get_world_size(group)
     items = sorted(local.items())
     desc = torch.full((n_total, 2), -1, dtype=torch.int64)
@@ -116,7 +153,7 @@ def gather_results(local, n_total, n_out, group=None, device="cpu"):
     return out
 
 
-def forward_sharded(forward_fn, structures, n_out, max_atoms=32768, group=None, device="cpu"):
+def forward_sharded(forward_fn, structures, n_out, max_atoms=32768, group=None, device=None):
     """Shard ``structures`` over the ranks of the (already initialised) process group, run them, gather all results
     on every rank.  Single-process (no process group): runs everything locally."""
     import torch.distributed as dist

@@ -56,11 +56,12 @@ def _to_numpy(v):
     return np.asarray(v)
 
 
-def flatten_state_dict(config, state_dict):
+def flatten_state_dict(config, state_dict, strict=True):
     """state_dict (torch tensors or numpy arrays, reference key names) -> flat float32 blob.
 
     Mirrors ``Module.load_state_dict`` strictness: a missing key or a shape mismatch raises
     KeyError / ValueError; ``m_nn`` and ``sdk`` entries are checked if present, then dropped.
+    ``strict=False`` tolerates unexpected keys (a missing parameter still raises: the blob must be complete).
     """
     c = normalise(config)
     parts = []
@@ -84,7 +85,7 @@ def flatten_state_dict(config, state_dict):
                 raise ValueError(f"{k} must be sqrt(Nk) (model_operations.py:85)")
     known = {k for k, _ in blob_schema(c)}
     extra = [k for k in state_dict if k not in known and not (k.endswith(".m_nn") or k.endswith(".su.sdk"))]
-    if extra:
+    if extra and strict:
         raise KeyError(f"unexpected key(s) in state_dict: {extra[:4]}")
     return np.concatenate(parts)
 

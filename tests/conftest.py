@@ -43,6 +43,9 @@ def weights(tag):
         from pesto_amd.weights import stack_layers
         if tag == "i_v4_1":
             _weights_cache[tag] = stack_layers(weights("i_v4_0"), CONFIGS["i_v4_1"], 0.5)
+        elif tag == "i_v3_1_trained":  # the reference's trained i_v3_1 (model/save/i_v3_1_2021-05-28_12-40/model.pt) as arrays
+            d = golden("weights_i_v3_1")
+            _weights_cache[tag] = {k: d[k] for k in d.files}
         elif tag == "i_v3_1":  # hybrid: own em/dm + i_v3_0 sum/spl (see tests/golden/make_golden.py)
             sd = dict(weights("i_v3_0"))
             d = golden("weights_i_v3_1_emdm")
@@ -53,6 +56,20 @@ def weights(tag):
             d = golden("weights_" + tag)
             _weights_cache[tag] = {k: d[k] for k in d.files}
     return _weights_cache[tag]
+
+
+# BASELINE config 4: chains of the reference's pdbs_test/ set whose reference outputs (i_v4_1 architecture, stacked weights) are
+# committed as cfg4_<name>.npz; pdbs_test_sizes.npz holds the atom / residue counts of all 53 chains
+CFG4_CHAINS = ("V9_2V9T_1_B_0", "JT_1JTD_1_B_0", "WU_2WUS_1_A_0", "SJ_3SJA_3_I_1", "NV_3NVN_1_A_0")
+
+
+def cfg4_structure(name):
+    """(X, ids_topk0 [N,64] 0-based, q0, M, z_ref) of one config-4 chain, in the per-structure contract of collate_batch_features."""
+    g = golden("cfg4_" + name)
+    roa = g["res_of_atom"].astype(np.int32)
+    M = np.zeros((roa.size, int(roa.max()) + 1), np.float32)
+    M[np.arange(roa.size), roa] = 1.0
+    return g["X"], g["ids_topk"].astype(np.int32) - 1, onehot(g["q_idx"], 30), M, g["z"]
 
 
 @pytest.fixture(scope="session")

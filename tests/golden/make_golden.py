@@ -317,6 +317,69 @@ def main_next():
          res_of_atom=res_of_atom(Mc), z=z)
 
 
+PDBS_TEST_GOLDEN = ("V9_2V9T_1_B:0", "JT_1JTD_1_B:0", "WU_2WUS_1_A:0", "SJ_3SJA_3_I:1", "NV_3NVN_1_A:0")
+
+
+def main_r2():
+    """Round-2 goldens: (1) BASELINE config 4 - chains of pdbs_test/ through the i_v4_1 architecture (stacked weights), one
+    structure per call like the reference's bulk loop (interfaceome/apply_model.py:57-82, apply_model.ipynb:139-167);
+    (2) the TRAINED i_v3_1 (model/save/i_v3_1_2021-05-28_12-40/model.py:10-22 + model.pt) on 2CUA, fp32 and fp64 - its
+    states reach 4e5, beyond the f16 range of the split-MFMA path; (3) BASELINE config 3 at its stated size (i_v3_0, N=3000)."""
+    import glob
+    # (1) config 4
+    cfg40, m40 = load_run("i_v4_0_2021-09-07_11-20")
+    cfg41, Model41, _ = import_reference("i_v4_1_2021-09-07_11-21")
+    m41 = Model41(cfg41).eval()
+    from pesto_amd.weights import stack_layers
+    sd41 = stack_layers({k: v.numpy() for k, v in m40.state_dict().items()}, cfg41, residual_scale=0.5)
+    print("i_v4_1 stacked", m41.load_state_dict({k: pt.from_numpy(np.array(v)) for k, v in sd41.items()}))
+    import_reference("i_v4_1_2021-09-07_11-21")
+    sizes = []
+    for f in sorted(glob.glob(os.path.join(REF, "pdbs_test", "*.pdb"))):
+        if f.endswith(("_M.pdb", "_T.pdb")):
+            continue
+        st = parse_pdb(f)
+        sizes.append((os.path.basename(f)[:-4], st["xyz"].shape[0], int(np.unique(st["resid"]).size)))
+    save("pdbs_test_sizes", names=np.array([s[0] for s in sizes]).astype("S"), atoms=np.array([s[1] for s in sizes], np.int32),
+         residues=np.array([s[2] for s in sizes], np.int32))
+    for name in PDBS_TEST_GOLDEN:
+        st = parse_pdb(os.path.join(REF, "pdbs_test", name + ".pdb"))
+        X, ids, q, M = encode(st, False)
+        Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+        z = run_forward(m41, Xc, idsc, qc, Mc)
+        print(f"  {name}: N={Xc.shape[0]} R={Mc.shape[1]} |z|max={np.abs(z).max():.2f}")
+        save("cfg4_" + name.replace(":", "_"), X=Xc.numpy(), ids_topk=idsc.numpy().astype(np.int16), q_idx=onehot_to_idx(qc, False),
+             res_of_atom=res_of_atom(Mc).astype(np.int16), z=z)
+    # (2) trained i_v3_1
+    cfg31, m31 = load_run("i_v3_1_2021-05-28_12-40")
+    save("weights_i_v3_1", **sd_arrays(m31))
+    st = parse_pdb(os.path.join(REF, "examples", "issue_19_04_2023", "2CUA_A.pdb"))
+    X, ids, q, M = encode(st, True)
+    Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+    z32 = run_forward(m31, Xc, idsc, qc, Mc)
+    with pt.no_grad():
+        z64 = m31.double()(Xc.double(), idsc, qc.double(), Mc.double()).numpy()
+        m31.float()
+        # state magnitude the layers reach (documented in DESIGN.md)
+        from src.model_operations import unpack_state_features
+        q1 = m31.em(qc)
+        qs, ids_s, D, R = unpack_state_features(Xc, idsc, q1)
+        state = (qs, pt.zeros((qs.shape[0], 3, qs.shape[1])), ids_s, D, R)
+        smax = []
+        for layer in m31.sum:
+            state = tuple(t.detach() for t in layer(state))
+            smax.append(max(float(state[0].abs().max()), float(state[1].abs().max())))
+    print(f"  i_v3_1 trained 2CUA: |z|max={np.abs(z32).max():.3e} fp32-vs-fp64 {np.abs(z32 - z64).max():.3e} state max {max(smax):.3e}")
+    save("fwd_i_v3_1_2CUA", z=z32, z64=z64, state_max=np.array(smax, np.float32))   # inputs: fwd_i_v3_0_2CUA.npz (same structure, same features)
+    # (3) config 3 at N=3000
+    cfg30, m30 = load_run("i_v3_0_2021-05-27_14-27")
+    X, ids, q, M = synth_inputs(3000, 1, n0=123)
+    Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+    z = run_forward(m30, Xc, idsc, qc, Mc)
+    print(f"  i_v3_0 N=3000: |z|max={np.abs(z).max():.3f}")
+    save("fwd_i_v3_0_synth3000", z=z, seed=np.int64(1))
+
+
 def _pdb_line(rec, serial, name, alt, resname, chain, resnum, icode, xyz, element, occ=1.0, b=20.0):
     name4 = name if len(name) == 4 else " " + name.ljust(3)
     return "%-6s%5d %4s%1s%3s %1s%4d%1s   %8.3f%8.3f%8.3f%6.2f%6.2f          %2s  " % (
@@ -436,7 +499,10 @@ if __name__ == "__main__":
         main_next()
     elif "--io" in sys.argv:
         main_io()
+    elif "--r2" in sys.argv:      # round-2 additions only
+        main_r2()
     else:
         main()
         main_next()
         main_io()
+        main_r2()

@@ -5,20 +5,25 @@ small stages and 1e-6 of the state scale for a layer (see stage_tol)."""
 import numpy as np
 import pytest
 
-from conftest import golden, onehot, weights
+from conftest import CFG4_CHAINS, cfg4_structure, golden, onehot, weights
 from pesto_amd.config import CONFIGS
 
 pytestmark = pytest.mark.gpu
 
 
+_IMPL = {"name": "mfma"}
+# layer implementation -> (Model precision, pesto_debug_select layer_kernels)
+_IMPL_ARGS = {"mfma": ("auto", 0), "mfma_records": ("auto", 5), "mfma_exact": ("fp32", 0), "v1": ("auto", 1)}
+
+
 @pytest.fixture(params=["mfma", "mfma_records", "mfma_exact", "v1"])
-def impl(request, monkeypatch):
-    """All layer implementations: the shipped MFMA path (hybrid first layer, big GEMMs on f16-split MFMA), the previous
-    default with full neighbour records (PESTO_EDGE_VARIANT=5), the same kernels on exact fp32 MFMA (PESTO_EDGE_VARIANT=1)
-    and the LDS-tiled VALU path (PESTO_IMPL=v1)."""
-    monkeypatch.setenv("PESTO_IMPL", "v1" if request.param == "v1" else "v2")
-    monkeypatch.setenv("PESTO_EDGE_VARIANT", {"mfma_exact": "1", "mfma_records": "5"}.get(request.param, "0"))
-    return request.param
+def impl(request):
+    """All layer implementations: the shipped MFMA path (hybrid first layer, big GEMMs on f16-split MFMA, precision "auto"), the
+    round-1 design with full neighbour records (debug twin 5), the same kernels on exact fp32 MFMA (precision "fp32" - also
+    what "auto" falls back to) and the LDS-tiled fp32 VALU kernel (debug twin 1)."""
+    _IMPL["name"] = request.param
+    yield request.param
+    _IMPL["name"] = "mfma"
 
 
 def stage_tol(ref):
@@ -27,9 +32,10 @@ def stage_tol(ref):
     return 1e-6 * (1.0 + float(np.abs(ref).max()))
 
 
-def _model(tag):
+def _model(tag, impl=None):
     from pesto_amd import Model
-    m = Model(CONFIGS[tag])
+    precision, twin = _IMPL_ARGS[impl or _IMPL["name"]]
+    m = Model(CONFIGS[tag], precision=precision).debug_select(twin)
     m.load_state_dict(weights(tag))
     return m.eval()
 
@@ -497,16 +503,14 @@ def test_batch_equals_singles_bitwise_across_kernel_instantiations():
 
 
 # ---------------------------------------------------------------------------------------------- k-NN cell grid (large structures)
-def _knn_both_paths(m, X, sizes, monkeypatch):
-    monkeypatch.delenv("PESTO_KNN_BRUTE", raising=False)
-    grid = m.knn_collate(X, sizes)
-    monkeypatch.setenv("PESTO_KNN_BRUTE", "1")
-    brute = m.knn_collate(X, sizes)
-    monkeypatch.delenv("PESTO_KNN_BRUTE", raising=False)
+def _knn_both_paths(m, X, sizes):
+    grid = m.debug_select(0, knn_brute_force=False).knn_collate(X, sizes)
+    brute = m.debug_select(0, knn_brute_force=True).knn_collate(X, sizes)
+    m.debug_select(0, knn_brute_force=False)
     return grid, brute
 
 
-def test_knn_cell_grid_equals_brute_force(monkeypatch):
+def test_knn_cell_grid_equals_brute_force():
     """Structures of >= 1024 atoms are searched through a uniform cell grid; the table must be the brute-force one, bit for bit:
     protein-like cloud, a mixed batch (large + small members), a flat slab (one cell layer), two dense blobs far apart (most
     cells empty, blocks must grow), and atoms on a line."""
@@ -519,12 +523,12 @@ def test_knn_cell_grid_equals_brute_force(monkeypatch):
     line = np.zeros((4500, 3), np.float32); line[:, 0] = np.arange(4500) * 1.3 + rng.uniform(0, 0.3, 4500)
     for X, sizes in ((cloud, [6000]), (np.concatenate([cloud[:4200], cloud[4200:5400], cloud[5400:], slab]), [4200, 1200, 600, 5000]),
                      (slab, [5000]), (blobs, [5000]), (line, [4500]), (cloud[:1024], [1024])):
-        grid, brute = _knn_both_paths(m, np.ascontiguousarray(X, np.float32), sizes, monkeypatch)
+        grid, brute = _knn_both_paths(m, np.ascontiguousarray(X, np.float32), sizes)
         assert np.array_equal(grid, brute)
         assert grid.min() >= 1 and grid.max() <= X.shape[0]
 
 
-def test_knn_cell_grid_vs_host_contract_and_forward(monkeypatch):
+def test_knn_cell_grid_vs_host_contract_and_forward():
     from pesto_amd.topology import extract_topology, synthetic_structure
     m = _model("i_v4_0")
     X, _, q, M = synthetic_structure(5000, 31, n0=30)
@@ -578,3 +582,133 @@ def test_knn_fewer_columns_than_64():
         full = m.knn_collate(X, [n])
         part = m.knn_collate(X, [n], k=16)
         assert np.array_equal(part[:, :16], full[:, :16]) and not part[:, 16:].any()
+
+
+# ---------------------------------------------------------------------------------------------- round 2: config 4, config 3 at size, range guard
+def test_config4_pdbs_test_chains_sharded_and_batched():
+    """BASELINE config 4: chains of the reference's pdbs_test/ (1,641 - 3,052 atoms) through the i_v4_1 architecture against the
+    reference's one-structure-per-call outputs, via sharding.forward_sharded (single process = world 1) and Model.forward_batch;
+    any grouping into launches gives the same bits (PESTO_BATCH_INDEPENDENT)."""
+    from pesto_amd.sharding import forward_sharded
+    m = _model("i_v4_1")
+    structs, refs = [], []
+    for name in CFG4_CHAINS:
+        X, ids0, q, M, z = cfg4_structure(name)
+        structs.append((X, ids0, q, M)); refs.append(z)
+    sharded = forward_sharded(m, structs, n_out=5, max_atoms=8000)          # launches of 3 + 2 chains
+    one_launch = m.forward_batch(structs, independent=True)
+    for i, z in enumerate(refs):
+        assert sharded[i].shape == z.shape and np.abs(sharded[i] - z).max() < 1e-4, CFG4_CHAINS[i]
+        assert np.array_equal(sharded[i], one_launch[i])
+        assert np.array_equal(sharded[i], m.forward_batch([structs[i]], independent=True)[0])
+    # the same chains as ONE collated batch with device tensors and per-structure semantics (what apply_model does)
+    import torch
+    from pesto_amd.topology import collate_batch_features, mask_to_segments
+    X, ids, q, M = collate_batch_features([list(s) for s in structs])
+    roa, R = mask_to_segments(M)
+    dev = torch.device("cuda:0")
+    zc = m.to(dev).forward_segments(torch.from_numpy(X).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(q).to(dev),
+                                    torch.from_numpy(roa).to(dev), R, sizes=[s[0].shape[0] for s in structs]).cpu().numpy()
+    assert np.array_equal(zc, np.concatenate(one_launch, 0))
+
+
+def test_config3_i_v3_0_at_n3000():
+    """BASELINE config 3 at its stated size (i_v3_0: 16 layers, 123 input features, real weights; synthetic N=3000)."""
+    from pesto_amd.topology import mask_to_segments, synthetic_structure
+    gs = golden("fwd_i_v3_0_synth3000")
+    X, ids0, q, M = synthetic_structure(3000, int(gs["seed"]), n0=123)
+    roa, R = mask_to_segments(M)
+    z = _model("i_v3_0").forward_segments(X, ids0 + 1, q, roa, R)
+    assert np.abs(z - gs["z"]).max() < 1e-4
+
+
+def test_trained_i_v3_1_range_guard():
+    """The reference's TRAINED i_v3_1 drives its states to 4e5, beyond the f16 range of the split-MFMA kernels. "auto" must notice
+    and repeat the forward on the exact fp32 kernels (finite, within the reference's own fp32-vs-fp64 noise); "f16_split" must fail
+    loudly (error on the synchronising path, all-NaN logits on the asynchronous one) - never a plausible wrong number."""
+    import torch
+    from pesto_amd import Model
+    from pesto_amd._lib import ERR_RANGE, PestoError
+    from test_oracle import i_v3_1_bound
+    g, ref = golden("fwd_i_v3_0_2CUA"), golden("fwd_i_v3_1_2CUA")
+    roa = g["res_of_atom"]
+    args = (g["X"], g["ids_topk"].astype(np.int64), onehot(g["q_idx"], 123), roa, int(roa.max()) + 1)
+    m = Model(CONFIGS["i_v3_1"])                                   # precision "auto" is the default
+    m.load_state_dict(weights("i_v3_1_trained"))
+    z_auto = m.forward_segments(*args)
+    st = m.status()
+    assert st["precision"] == "auto" and st["n_fp32_rerun"] == 1 and st["n_forward"] == 2
+    assert z_auto.shape == ref["z"].shape and i_v3_1_bound(z_auto, ref)
+    m.set_precision("fp32")
+    z_fp32 = m.forward_segments(*args)
+    assert np.array_equal(z_fp32, z_auto) and m.status()["n_fp32_rerun"] == 1
+    # device tensors: auto synchronises, checks and repeats as well
+    dev = torch.device("cuda:0")
+    m.set_precision("auto").to(dev)
+    targs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in args[:4]]
+    z_dev = m.forward_segments(*targs, args[4])
+    assert np.array_equal(z_dev.cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 2
+    # f16_split: loud failure
+    m.set_precision("f16_split")
+    with pytest.raises(PestoError) as e:
+        m.forward_segments(*args)
+    assert e.value.code == ERR_RANGE
+    z_nan = m.forward_segments(*targs, args[4])                    # asynchronous and unchecked: every logit NaN
+    assert torch.isnan(z_nan).all()
+    # the handle is not poisoned: a well-behaved model state afterwards
+    m.set_precision("auto")
+    assert np.array_equal(m.to("cpu").forward_segments(*args), z_auto)
+    # and a model that stays in range never pays for the guard
+    m40 = _model("i_v4_0", "mfma")
+    g40 = golden("fwd_i_v4_0_2CUA")
+    m40.forward_segments(g40["X"], g40["ids_topk"], onehot(g40["q_idx"], 30), g40["res_of_atom"], g40["z"].shape[0])
+    assert m40.status() == {"precision": "auto", "n_forward": 1, "n_fp32_rerun": 0}
+
+
+def test_forward_batch_independent_equals_one_call_per_structure():
+    """PESTO_BATCH_INDEPENDENT: structures with fewer than 64 atoms (zero-padded neighbour slots wrap to the structure's OWN last
+    atom) and with coincident atoms (max(D) of the structure, not of the batch) get exactly the result of their own call,
+    whatever they are batched with; PESTO_BATCH_COLLATED reproduces the reference's collated forward instead (edge_batch2)."""
+    from pesto_amd.topology import extract_topology, synthetic_structure
+    m = _model("i_v4_0")
+    structs = _split_batch_fixture(golden("edge_batch2"))           # 300 + 40 atoms
+    g = golden("edge_coincident")                                    # 150 atoms, D < 1e-2 entries inside the table
+    roa = g["res_of_atom"]
+    Mc = np.zeros((roa.size, int(roa.max()) + 1), np.float32); Mc[np.arange(roa.size), roa] = 1
+    structs.append((g["X"], g["ids_topk"].astype(np.int32) - 1, onehot(g["q_idx"], 30), Mc))
+    X, _, q, M = synthetic_structure(17, 3)
+    structs.append((X, extract_topology(X, 64), q, M))
+    singles = [m.forward_batch([s])[0] for s in structs]
+    for order in ((0, 1, 2, 3), (3, 2, 1, 0), (1, 3, 0, 2)):
+        zb = m.forward_batch([structs[i] for i in order], independent=True)
+        for pos, i in enumerate(order):
+            assert np.array_equal(zb[pos], singles[i]), (order, i)
+    assert np.abs(singles[2] - g["z"]).max() < 1e-4                # a structure alone = the reference's own call
+    collated = m.forward_batch(structs)
+    assert not np.array_equal(collated[1], singles[1])              # the reference's batch coupling (N = 40 wraps to the batch's last atom)
+    assert np.array_equal(collated[0], singles[0])
+
+
+def test_calls_on_different_streams_share_the_workspace_safely():
+    """One handle = one workspace. A forward queued on a torch side stream, a host-pointer call (the model's own stream) and a
+    forward on the default stream, issued back to back without synchronising in between, must not overwrite each other."""
+    import torch
+    g = golden("fwd_i_v4_0_2AYO")
+    g2 = golden("fwd_i_v4_0_2CUA")
+    m = _model("i_v4_0", "mfma").set_precision("f16_split")          # asynchronous device-pointer calls
+    dev = torch.device("cuda:0")
+    m.to(dev)
+    a = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (g["X"], g["ids_topk"].astype(np.int64), onehot(g["q_idx"], 30), g["res_of_atom"])]
+    b = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (g2["X"], g2["ids_topk"].astype(np.int64), onehot(g2["q_idx"], 30), g2["res_of_atom"])]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            z_side = m.forward_segments(*a, g["z"].shape[0])
+        z_host = m.forward_segments(g2["X"], g2["ids_topk"], onehot(g2["q_idx"], 30), g2["res_of_atom"], g2["z"].shape[0])
+        z_def = m.forward_segments(*b, g2["z"].shape[0])
+        with torch.cuda.stream(side):
+            z_side2 = m.forward_segments(*a, g["z"].shape[0])
+        torch.cuda.synchronize()
+        assert np.abs(z_side.cpu().numpy() - g["z"]).max() < 1e-4 and torch.equal(z_side, z_side2)
+        assert np.abs(z_host - g2["z"]).max() < 1e-4 and np.array_equal(z_def.cpu().numpy(), z_host)

@@ -87,7 +87,76 @@ def test_failed_structure_is_skipped_not_fatal():
     def flaky(X, ids, q, M):
         calls["n"] += 1
         if np.asarray(X).shape[0] in (96, 70 + 96):      # batch containing structure 1, and structure 1 alone
-            raise RuntimeError("boom")
+            raise ValueError("boom")
         return np.zeros((np.asarray(M).shape[1], 5), np.float32)
     res = sharding.forward_local(flaky, structures, [0, 1, 2], max_atoms=170)
     assert res[1] is None and res[0] is not None and res[2] is not None
+
+
+def test_systemic_failure_propagates():
+    """Only per-structure input errors (PestoError / ValueError) are skipped; anything else, or a rank on which EVERY structure
+    fails, is an error of the run, not of a structure."""
+    structures = _structures()[:2]
+
+    def broken(X, ids, q, M):
+        raise OSError("library missing")
+    with pytest.raises(OSError):
+        sharding.forward_local(broken, structures, [0, 1], max_atoms=100)
+
+    def all_bad(X, ids, q, M):
+        raise ValueError("bad input")
+    with pytest.raises(ValueError):
+        sharding.forward_local(all_bad, structures, [0, 1], max_atoms=100)
+
+
+# ---------------------------------------------------------------------------------------------- on the GPU box
+def _hip_structures():
+    from pesto_amd.topology import extract_topology, synthetic_structure
+    out = []
+    for i, n in enumerate((700, 90, 1300, 40, 260, 1100, 64, 500)):
+        X, _, q, M = synthetic_structure(n, 300 + i)
+        out.append((X, extract_topology(X, 64), q, M))
+    return out
+
+
+def _hip_model():
+    from pesto_amd import Model
+    m = Model(CONFIGS["i_v4_0"])
+    m.load_state_dict(weights("i_v4_0"))
+    return m
+
+
+def _hip_worker(rank, world, port, out_dir, backend):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)                       # a 1-GPU box: every rank drives GPU 0 (gloo carries the collectives)
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        res = sharding.forward_sharded(_hip_model().to("cuda:0"), _hip_structures(), n_out=5, max_atoms=2000)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{str(i): z for i, z in enumerate(res)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+def test_sharded_hip_forward_equals_single_process_bitwise(tmp_path, backend, world):
+    """The REAL path under torch.distributed: ranks shard the structures, run them through libpesto_hip.so and gather every
+    result. gloo / world 2 (both ranks on the box's one GPU) exercises the partition + ragged gather across processes; nccl /
+    world 1 exercises the RCCL collectives with device tensors (what an 8-GPU node uses). Either way every structure must come
+    back with exactly the bits of a plain single-process run, including the N < 64 members (PESTO_BATCH_INDEPENDENT)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_hip_worker, args=(world, port, str(tmp_path), backend), nprocs=world, join=True)
+    structures = _hip_structures()
+    m = _hip_model()
+    single = [m.forward_batch([st])[0] for st in structures]         # one call per structure
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+        assert len(got.files) == len(structures)
+        for i in range(len(structures)):
+            assert np.array_equal(got[str(i)], single[i]), (rank, i)
