@@ -2,13 +2,15 @@
 # PMC collection for the bench workload: separate rocprofv3 --pmc passes (no tracing combined), per
 # /opt/skills/guides/MI355X_MICROARCH.md (SQ 8 slots, TCC 4 slots; FETCH_SIZE costs 3, WRITE_SIZE 2).
 # usage: profiles/pmc_collect.sh <tag>   (run on the GPU box from the repo root; writes gpurun_out/pmc_<tag>/)
+# gpurun_out/pmc_<tag>/traffic.json is stamped with the sha256 of the kernel sources and the kernel symbols it saw; copy it to
+# profiles/traffic_i_v4_1_n3000_b8.json - bench.py quotes roofline.traffic from that file only while the hash matches the tree.
 set -u
 TAG=${1:-run}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
 mkdir -p $R/gpurun_out/pmc_$TAG
-CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-latency"
+CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-latency --no-extras --precision f16_split"
 i=0
 for SET in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
@@ -20,9 +22,10 @@ do
   i=$((i+1))
   timeout 240 rocprofv3 --pmc $SET -d $R/gpurun_out/pmc_$TAG/p$i -o pmc --output-format csv -- $CMD > $R/gpurun_out/pmc_$TAG/p$i.log 2>&1 || echo "pass $i failed"
 done
-python - "$R/gpurun_out/pmc_$TAG" <<'PY'
+python - "$R/gpurun_out/pmc_$TAG" "$R" <<'PY'
 import csv, glob, sys, collections
 root = sys.argv[1]
+sys.path.insert(0, sys.argv[2])
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
@@ -51,7 +54,9 @@ for k in agg:
         w = agg[k].get("WRITE_SIZE", 0.0) / nw * 1024.0
         per[k.strip()] = {"fetch_bytes_per_dispatch_raw": f, "write_bytes_per_dispatch": w, "dispatches_per_forward": calls}
         tot_f += f * calls; tot_w += w * calls
-out = {"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for 16 B/lane reads); WRITE_SIZE uncorrected",
+from bench import source_hash
+out = {"source_hash": source_hash(), "kernel_symbols": sorted(per),
+       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for 16 B/lane reads); WRITE_SIZE uncorrected",
        "fetch_bytes_per_forward_raw": tot_f, "fetch_bytes_per_forward_corrected": 2 * tot_f, "write_bytes_per_forward": tot_w,
        "hbm_bytes_per_forward": 2 * tot_f + tot_w, "kernels": per}
 json.dump(out, open(root + "/traffic.json", "w"), indent=1)
