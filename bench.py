@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--precision", default="auto", choices=["auto", "f16_split", "fp32"], help="pesto_precision of the timed steps")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency side measurement")
+    ap.add_argument("--no-check", action="store_true", help="developer ablation builds only: do not check the timed output")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 and config-4 legs (profiling runs)")
     ap.add_argument("--config4-structures", type=int, default=64)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
@@ -289,13 +290,13 @@ def main():
         return el, z_
 
     elapsed, z = timed(args.warmup, args.steps)
-    assert torch.isfinite(z).all()
+    assert args.no_check or torch.isfinite(z).all()
     status = model.status()
 
     # ---- the timed output against the reference: structure 0 of rank 0 is the committed golden (seed 1, N=3000, i_v4_1 stacked)
     parity = None
     gpath = os.path.join(ROOT, "tests", "golden", "fwd_i_v4_1_stacked_synth3000.npz")
-    if rank == 0 and args.config == "i_v4_1" and args.atoms == 3000 and args.order == "random" and os.path.exists(gpath):
+    if rank == 0 and args.config == "i_v4_1" and args.atoms == 3000 and args.order == "random" and os.path.exists(gpath) and not args.no_check:
         zg = np.load(gpath)["z"]
         parity = float(np.abs(z[:zg.shape[0]].cpu().numpy() - zg).max())
         assert parity < 1e-4, f"timed output differs from the reference golden by {parity}"

@@ -217,7 +217,21 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
         return hipEventRecord(m->kev[kevi++], st);
     };
     auto nn_class = [](int nn) { return nn == 8 ? 1 : nn == 16 ? 2 : nn == 32 ? 3 : 4; };
-    if (m->impl == 2) {
+    if (m->impl == 2 && edge_variant == 0) {
+        // shipped path, per layer: node kernel (records of layer l from the current state), edge kernel with the finish phase
+        // inside (new state into the other half of the ping-pong pair)
+        for (int l = 0; l < m->cfg.n_layers; ++l) {
+            HIP_TRY(mark(0));
+            launch_node(st, m->W, nullptr, &m->img.layers[l], N1, q[cur], p[cur], m->zrec.as<float>(), m->rec_nb.as<float>(),
+                        m->rec_cen.as<float>(), edge_variant, err_ptr(m));
+            HIP_TRY(mark(nn_class(m->cfg.nn[l])));
+            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(),
+                        m->rec_cen.as<float>(), p[cur], nullptr, m->edge_blocks, edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1]);
+            cur ^= 1;
+        }
+        HIP_TRY(mark(-1));
+        if (detail) { m->kev.resize(kevi); m->kev_class.resize(kevi); }
+    } else if (m->impl == 2) {
         // per layer: node kernel (finish layer l-1, write layer l's records) then edge kernel; state updated in place
         for (int l = 0; l < m->cfg.n_layers; ++l) {
             HIP_TRY(mark(0));
@@ -240,7 +254,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     }
     if (m->timing) {
         HIP_TRY(hipEventRecord(m->ev[2], st));
-        m->n_layer_launches = m->impl == 2 ? 2 * m->cfg.n_layers + 1 : m->cfg.n_layers;
+        m->n_layer_launches = m->impl != 2 ? m->cfg.n_layers : edge_variant == 0 ? 2 * m->cfg.n_layers : 2 * m->cfg.n_layers + 1;
         m->have_timing = true;
     }
     launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)NT, (int)RT, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
@@ -756,9 +770,14 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
         const LayerW* L = &m->img.layers[layer];
         const int ev = m->precision == PESTO_PRECISION_FP32 ? 1 : m->fast_variant;     // no automatic re-run at stage level
         launch_node(st, m->W, nullptr, L, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), ev, err_ptr(m));
-        launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->edge_blocks, ev, err_ptr(m));
-        launch_node(st, m->W, L, nullptr, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), ev, err_ptr(m));
-        q_res = m->q_a.p; p_res = m->p_a.p;
+        if (ev == 0) {      // shipped path: the finish phase runs inside the edge kernel, new state in the other buffer pair
+            launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), nullptr, m->edge_blocks, ev, err_ptr(m),
+                        m->q_a.as<float>(), m->q_b.as<float>(), m->p_b.as<float>());
+        } else {
+            launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->edge_blocks, ev, err_ptr(m));
+            launch_node(st, m->W, L, nullptr, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), ev, err_ptr(m));
+            q_res = m->q_a.p; p_res = m->p_a.p;
+        }
     } else {
         launch_layer_v1(st, m->W, m->img.layers[layer], (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->q_a.as<float>(), m->p_a.as<float>(),
                         m->q_b.as<float>(), m->p_b.as<float>());

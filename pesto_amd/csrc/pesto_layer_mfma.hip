@@ -520,13 +520,17 @@ __device__ __forceinline__ float row_reduce(float x) {
     return x;
 }
 
+// workgroup rendezvous that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load of the wave
+// (vmcnt(0)), which would expose the latency of the loads the finish phase deliberately issues ahead of the rendezvous
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // =============================================================================================== edge kernel
 #ifdef PESTO_PROFILE_PHASES   // developer build: per-phase wave cycles (s_memtime), printed by pesto_destroy
-__device__ unsigned long long g_phase_cycles[8];
+__device__ unsigned long long g_phase_cycles[12];
 #define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); phase_acc_[k] += now_ - tmark_; tmark_ = now_; } while (0)
 #define PHASE_INIT() tmark_ = __builtin_readcyclecounter()
-#define PHASE_DECL() unsigned long long tmark_ = 0, phase_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define PHASE_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_phase_cycles[k_], phase_acc_[k_]); } while (0)
+#define PHASE_DECL() unsigned long long tmark_ = 0, phase_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_phase_cycles[k_], phase_acc_[k_]); } while (0)
 #else
 #define PHASE_MARK(k) do {} while (0)
 #define PHASE_INIT() do {} while (0)
@@ -711,17 +715,27 @@ __device__ __forceinline__ void l1_tile_lean(int fb0, int lane, int g, const Til
     }
 }
 
-template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4>
+// FIN (finish in the edge kernel): the attention sums Z of a centre never leave the CU. Every wave leaves the complete Z rows of
+// its (at most two) centres in its LDS scratch; behind a workgroup barrier four waves per 16 centres apply the output MLPs on
+// the matrix cores - role 0: q += qpm(Zq), roles 1..3: p[c] += ppm(Zp[c]) (model_operations.py:147-152), sink reset (:239-240) -
+// with the weight fragments streamed from L2, and write the NEW state into the other half of a ping-pong pair (neighbours'
+// p_j of the old state are still being gathered by other workgroups). The node kernel then only prepares records.
+template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4, bool FIN = false>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
-                                                 const float* __restrict__ p_state, float* __restrict__ Z, int* __restrict__ flags) {
+                                                 const float* __restrict__ p_state, float* __restrict__ Z, int* __restrict__ flags,
+                                                 const float* __restrict__ q_state, float* __restrict__ q_out, float* __restrict__ p_out) {
     // TI = 16-edge tiles per wave work item: 4 (64 edge rows) for full launches; small launches (one structure) use finer
     // items - 1 tile for nn = 8 / 16, 2 for nn = 32 - so that the launch is spread over more waves and CUs (latency)
     constexpr int A = 16 * TI / NN;            // whole centres per work item
     constexpr int TPC = NN >= 16 ? NN / 16 : 1;   // tiles per centre
     static_assert(TI >= TPC && TI % TPC == 0 && A >= 1 && (!PF || TI == 4), "a work item holds whole centres");
     static_assert(!HY || (F16 && !PF), "the hybrid first layer exists on the lean f16-split path only");
+    static_assert(!FIN || (HY && A <= 2 && WPB >= 8), "finish phase: at most two staged centres per wave, four waves per 16-centre tile");
+    // FIN: work items a wave processes between two finish phases - as many as its two staging rows hold centres (nn = 64: two
+    // one-centre items), which halves the number of workgroup rendezvous
+    constexpr int SUBS = FIN ? 2 / A : 1;
     __shared__ EdgeSmem<WPB, HY> sm;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = lane & 15, g = lane >> 4;
@@ -745,7 +759,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     const int w_end = min(n_work, (xcd + 1) * chunk);
     PHASE_DECL();
     float sat = 0.0f;       // range guard of the f16-split path (sat_probe)
-    for (int work = xcd * chunk + jb * WPB + wave; work < w_end; work += nbx * WPB) {
+    // the trip count is the same for every wave of a workgroup (FIN: workgroup barriers inside); a wave without a work item idles
+    for (int base = xcd * chunk + jb * WPB * SUBS; base < w_end; base += nbx * WPB * SUBS) {
+#pragma unroll 1
+      for (int sub = 0; sub < SUBS; ++sub) {
+      const int work = base + sub * WPB + wave;
+      if (work < w_end) {
         const int c0 = work * A;
         PHASE_INIT();
         {   // rows of this work item: lane = row
@@ -1169,8 +1188,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     z3a[h] = f32x4{0, 0, 0, 0}; z3b[h] = f32x4{0, 0, 0, 0};
                 }
             }
+            const int slot0 = (FIN && NN >= 16) ? (SUBS > 1 ? sub : (16 * t) / NN) : 0;     // FIN keeps every centre of the iteration staged
             if (g == 0 || (NN == 8 && g == 2)) {
-                float* zb = ws.zbuf[(NN == 8 && g == 2) ? 1 : 0];
+                float* zb = ws.zbuf[(NN == 8 && g == 2) ? 1 : slot0];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1185,7 +1205,16 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             for (int sel = 0; sel < (NN == 8 ? 2 : 1); ++sel) {
                 const int a = NN == 8 ? 2 * t + sel : (16 * t) / NN;
                 const int i = c0 + a;
-                if (i < N1) {
+                if (FIN) {   // complete the row in place (every lane touches only its own elements)
+                    float* zb = ws.zbuf[NN == 8 ? sel : slot0];
+                    const int c = lane >> 5, s = lane & 31;
+                    const float pi0 = pi_pre[sel][0], pi1 = pi_pre[sel][1];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        zb[64 + c * 64 + h * 32 + s] += ws.wsum[a][h] * pi0 + ws.z3buf[sel][h][lane];
+                        if (lane < 32) zb[64 + 128 + h * 32 + lane] += ws.wsum[a][h] * pi1 + ws.z3buf[sel][h][64 + lane];
+                    }
+                } else if (i < N1) {
                     const float* zb = ws.zbuf[sel];
                     float* zo = Z + (size_t)i * REC_Z;
                     zo[lane] = zb[lane];
@@ -1209,6 +1238,124 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             __builtin_amdgcn_wave_barrier();
             PHASE_MARK(6);
         }
+      }   // work item
+      }   // sub
+      if (FIN) {
+        // ---- finish phase. Four waves per 16 staged centres; three steps so that the other waves wait as little as possible:
+        //   (1) before the barrier: this wave's weight fragments -> registers (one L2 round trip, overlapped with the stragglers);
+        //   (2) between two barriers: the staged Z rows -> registers (as f16 hi/lo B operands), old state loads issued;
+        //   (3) behind the second barrier (the LDS rows are free again, the other waves are already in their next work item):
+        //       the MFMA chains and the state update.
+        constexpr int CPW = A * SUBS;           // staged centres per wave (1 or 2)
+        constexpr int NB = WPB * CPW, NTILE = (NB + 15) / 16;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // uniform for the compiler too: scalar branches around the role code
+        PHASE_INIT();
+        if (wave_u < 4 * NTILE) {
+            const int tile = wave_u >> 2, role = wave_u & 3;
+            // lane index re-materialised behind an opaque barrier: otherwise the per-lane addresses of this phase (and the weight loads
+            // themselves) are hoisted out of the work loop as loop invariants and spilled - the main loop runs at the 168-VGPR limit
+            int lane_f = lane;
+            asm volatile("" : "+v"(lane_f));
+            const int fe = lane_f & 15, fg = lane_f >> 4;
+            // Every global load of this phase - weight fragments, biases, the OLD state of this column's centre - is issued BEFORE the
+            // rendezvous: behind it a load queues up after the gathers the other waves have issued meanwhile (microseconds under load
+            // per dependent round trip). The centre of a column follows from the work-item arithmetic, no LDS needed.
+            const int cslot = 16 * tile + fe;   // centre slot of this MFMA column: wave cslot / CPW, staged row cslot % CPW
+            const bool cv = cslot < NB;
+            const int cw = cv ? cslot / CPW : 0, cr = cv ? cslot % CPW : 0;
+            const int cwork = base + (SUBS > 1 ? cr * WPB : 0) + cw;
+            const int ci_raw = cwork * A + (SUBS > 1 ? 0 : cr);
+            const bool valid = cv && cwork < w_end && ci_raw < N1;
+            const int ci = valid ? ci_raw : 0;
+            const float* zr = sm.ws[cw].zbuf[cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
+            const float* fb = W + lw.h_q0 + lane_f * 4;     // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
+            f16x8 zh[2], zl[2];
+            auto rows = [&]() {                 // the staged Z rows of this role as f16 hi/lo B operands (K = 64: two k-groups)
+#pragma unroll
+                for (int kgp = 0; kgp < 2; ++kgp) {
+                    f32x4 a0 = ld4(zr + 32 * kgp + 4 * fg), a1 = ld4(zr + 32 * kgp + 16 + 4 * fg);
+                    if (!valid) { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }     // unused columns: no stale LDS bits into the range guard
+                    split8(a0, a1, zh[kgp], zl[kgp]);
+                }
+            };
+            // acc[m] += W[m-block] x (K = 32 k-group): three products of the hi/lo split; fragments fr[(m, hi|lo)]
+#define PESTO_FIN_MFMA(acc, fr, xh_, xl_)                                                   \
+    {                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xh_, acc[m]);     \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xl_, acc[m]);     \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m + 1], xh_, acc[m]); \
+    }
+            f32x4 st[2], h[2];
+            if (role == 0) {   // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147, :151)
+                f16x8 w0[2][4], w1[4], w2[4];            // [kgp][(m, hi|lo)], [(m, hi|lo)]
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) { w0[kgp][2 * m] = ld8h(fb + ((m * 2 + kgp) * 2) * 256); w0[kgp][2 * m + 1] = ld8h(fb + ((m * 2 + kgp) * 2 + 1) * 256); }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) { w1[f] = ld8h(fb + (8 + f) * 256); w2[f] = ld8h(fb + (12 + f) * 256); }
+                f32x4 b1v[2], b2v[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    h[m] = ld4(W + lw.n_bq0 + 16 * m + 4 * fg); b1v[m] = ld4(W + lw.n_bq1 + 16 * m + 4 * fg); b2v[m] = ld4(W + lw.n_bq2 + 16 * m + 4 * fg);
+                    st[m] = ld4(q_state + (size_t)ci * S + 16 * m + 4 * fg);
+                }
+                PHASE_MARK(7);
+                lds_barrier();                         // every wave's Z rows are staged
+                PHASE_MARK(8);
+                rows();
+                lds_barrier();                         // the staged rows may be overwritten by the next iteration
+                PHASE_MARK(9);
+                // the other waves are entering their next work item and raise their priority to 1 during MFMA bursts: at priority 0 this
+                // short chain would run behind them and make its wave the straggler of the next rendezvous
+                __builtin_amdgcn_s_setprio(2);
+                PESTO_FIN_MFMA(h, w0[0], zh[0], zl[0])
+                PESTO_FIN_MFMA(h, w0[1], zh[1], zl[1])
+                sat_probe(sat, h[0][0]);
+                f16x8 xh, xl;
+                split8(elu4(h[0]), elu4(h[1]), xh, xl);
+                PESTO_FIN_MFMA(b1v, w1, xh, xl)
+                sat_probe(sat, b1v[0][0]);
+                split8(elu4(b1v[0]), elu4(b1v[1]), xh, xl);
+                PESTO_FIN_MFMA(b2v, w2, xh, xl)
+                h[0] = b2v[0]; h[1] = b2v[1];
+            } else {           // ppm: 64 -> 32, no bias, xyz component role - 1             (:148, :152)
+                f16x8 wp[2][4];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) { wp[kgp][2 * m] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2) * 256); wp[kgp][2 * m + 1] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2 + 1) * 256); }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) st[m] = ld4(p_state + (size_t)ci * 96 + (role - 1) * 32 + 16 * m + 4 * fg);
+                PHASE_MARK(7);
+                lds_barrier();
+                PHASE_MARK(8);
+                rows();
+                lds_barrier();
+                PHASE_MARK(9);
+                __builtin_amdgcn_s_setprio(2);
+                h[0] = f32x4{0, 0, 0, 0}; h[1] = h[0];
+                PESTO_FIN_MFMA(h, wp[0], zh[0], zl[0])
+                PESTO_FIN_MFMA(h, wp[1], zh[1], zl[1])
+            }
+#undef PESTO_FIN_MFMA
+#pragma unroll
+            for (int m = 0; m < 2; ++m) st[m] += h[m];
+            sat_probe(sat, st[0][0]);          // (unused columns were fed zeros and the sink row's finite state)
+            if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
+            if (valid) {
+                float* dst = role == 0 ? q_out + (size_t)ci * S : p_out + (size_t)ci * 96 + (role - 1) * 32;
+                st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            PHASE_MARK(10);
+        } else {       // waves without a finish role: the two rendezvous only
+            lds_barrier();
+            PHASE_MARK(8);
+            lds_barrier();
+            PHASE_MARK(9);
+        }
+      }
     }
     if (F16) sat_flush(sat, flags);
     PHASE_FLUSH();
@@ -1216,12 +1363,13 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 
 void debug_print_phase_cycles() {
 #ifdef PESTO_PROFILE_PHASES
-    unsigned long long h[8];
+    unsigned long long h[12];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_cycles), sizeof h) == hipSuccess) {
-        const char* names[8] = {"setup", "pass1(keys)", "softmax", "p2:L1+L2", "p2:L3(values)", "p2:accumulate", "p2:finalize", "-"};
+        const char* names[12] = {"setup", "pass1(keys)", "softmax", "p2:L1+L2", "p2:L3(values)", "p2:accumulate", "p2:finalize", "fin:issue", "fin:barrier1",
+                                 "fin:rows+barrier2", "fin:compute", "-"};
         double tot = 0;
-        for (int k = 0; k < 7; ++k) tot += (double)h[k];
-        for (int k = 0; k < 7; ++k) fprintf(stderr, "[pesto phase] %-16s %6.2f %%  (%llu)\n", names[k], 100.0 * h[k] / tot, h[k]);
+        for (int k = 0; k < 11; ++k) tot += (double)h[k];
+        for (int k = 0; k < 11; ++k) fprintf(stderr, "[pesto phase] %-16s %6.2f %%  (%llu)\n", names[k], 100.0 * h[k] / tot, h[k]);
     }
 #endif
 }
@@ -1247,48 +1395,66 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
         hipLaunchKernelGGL(k_node16<false>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags);
 }
 
-template <int NN, int WPB, bool PF, bool F16, bool HY, int TI>
-static void launch_edge_k(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo, const float* rec_nb,
-                          const float* rec_cen, const float* p_state, float* Z, int max_blocks, int* flags) {
+struct EdgeIO {     // per-launch pointers of the edge kernel
+    const int* ids_s; const float4* geo; const float* rec_nb; const float* rec_cen; const float* p_state; float* Z; int* flags;
+    const float* q_state; float* q_out; float* p_out;      // FIN only: old q state, the other half of the ping-pong pair
+};
+
+template <int NN, int WPB, bool PF, bool F16, bool HY, int TI, bool FIN = false>
+static void launch_edge_k(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks) {
     constexpr int A = 16 * TI / NN;
     const int n_work = (N1 + A - 1) / A;
     int blocks = ((n_work + 7) / 8 + WPB - 1) / WPB * 8;   // per-XCD share of the work items, WPB per workgroup, x 8 XCDs
     if (blocks > max_blocks) blocks = max_blocks / 8 * 8;
     if (blocks < 8) blocks = 8;
-    hipLaunchKernelGGL((k_edge<NN, WPB, PF, F16, HY, TI>), dim3(blocks), dim3(WPB * 64), 0, st, W, lw, N1, n_work, ids_s, geo, rec_nb, rec_cen,
-                       p_state, Z, flags);
+    hipLaunchKernelGGL((k_edge<NN, WPB, PF, F16, HY, TI, FIN>), dim3(blocks), dim3(WPB * 64), 0, st, W, lw, N1, n_work, io.ids_s, io.geo, io.rec_nb,
+                       io.rec_cen, io.p_state, io.Z, io.flags, io.q_state, io.q_out, io.p_out);
 }
 
 // FINE = false: 64-row work items for every nn; FINE = true: the finest work item that still holds whole centres
 template <int WPB, bool PF, bool F16, bool HY = false, bool FINE = false>
-static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
-                          const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int* flags) {
+static void launch_edge_t(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks) {
     switch (lw.nn) {
-        case 8: launch_edge_k<8, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags); break;
-        case 16: launch_edge_k<16, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags); break;
-        case 32: launch_edge_k<32, WPB, PF, F16, HY, FINE ? 2 : 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags); break;
-        default: launch_edge_k<64, WPB, PF, F16, HY, 4>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags); break;
+        case 8: launch_edge_k<8, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, io, max_blocks); break;
+        case 16: launch_edge_k<16, WPB, PF, F16, HY, FINE ? 1 : 4>(st, W, lw, N1, io, max_blocks); break;
+        case 32: launch_edge_k<32, WPB, PF, F16, HY, FINE ? 2 : 4>(st, W, lw, N1, io, max_blocks); break;
+        default: launch_edge_k<64, WPB, PF, F16, HY, 4>(st, W, lw, N1, io, max_blocks); break;
+    }
+}
+
+// finish-in-edge instantiations of the shipped (hybrid f16-split) kernel: a work item holds at most two centres
+template <int WPB, bool FINE>
+static void launch_edge_fin(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks) {
+    switch (lw.nn) {
+        case 8: launch_edge_k<8, WPB, false, true, true, 1, true>(st, W, lw, N1, io, max_blocks); break;
+        case 16: launch_edge_k<16, WPB, false, true, true, FINE ? 1 : 2, true>(st, W, lw, N1, io, max_blocks); break;
+        case 32: launch_edge_k<32, WPB, false, true, true, FINE ? 2 : 4, true>(st, W, lw, N1, io, max_blocks); break;
+        default: launch_edge_k<64, WPB, false, true, true, 4, true>(st, W, lw, N1, io, max_blocks); break;
     }
 }
 
 // variant 0 (default): hybrid first layer (A_j record + per-edge p_j.r block on MFMA), 12 waves per workgroup (3 per SIMD, one
-//            workgroup per CU), f16-split MFMA
+//            workgroup per CU), f16-split MFMA; with q_out / p_out the finish phase runs inside (new state -> q_out / p_out)
 // variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch), full 2 KB neighbour records
-// variant 5: the previous default - full neighbour records, register-lean VALU first layer, f16-split MFMA, 12 waves per workgroup
+// variant 5: the round-1 design - full neighbour records, register-lean VALU first layer, f16-split MFMA, 12 waves per workgroup
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
-                 const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags) {
+                 const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags,
+                 const float* q_state, float* q_out, float* p_out) {
+    const EdgeIO io{ids_s, geo, rec_nb, rec_cen, p_state, Z, flags, q_state, q_out, p_out};
     // small launches (one structure, or the nn = 8/16 layers of a small batch) cannot fill 256 twelve-wave workgroups:
     // the same kernel body in smaller workgroups spreads them over more CUs
     const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
     if (variant == 1) {
-        launch_edge_t<4, true, false>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags);
+        launch_edge_t<4, true, false>(st, W, lw, N1, io, max_blocks);
     } else if (variant == 5) {
-        if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256, flags);
-        else launch_edge_t<4, false, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, max_blocks, flags);
+        if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, io, 256);
+        else launch_edge_t<4, false, true>(st, W, lw, N1, io, max_blocks);
+    } else if (q_out) {
+        if (n_work >= 2048) launch_edge_fin<12, false>(st, W, lw, N1, io, 256);
+        else launch_edge_fin<8, true>(st, W, lw, N1, io, 256);
     } else {
-        if (n_work >= 2048) launch_edge_t<12, false, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256, flags);
-        else launch_edge_t<8, false, true, true, true>(st, W, lw, N1, ids_s, geo, rec_nb, rec_cen, p_state, Z, 256, flags);   // 63 KB of constants: one
-                                                                                                   // workgroup per CU; fine work items
+        if (n_work >= 2048) launch_edge_t<12, false, true, true>(st, W, lw, N1, io, 256);
+        else launch_edge_t<8, false, true, true, true>(st, W, lw, N1, io, 256);   // 63 KB of constants: one workgroup per CU; fine work items
     }
 }
 

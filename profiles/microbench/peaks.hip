@@ -26,36 +26,37 @@ __global__ __launch_bounds__(256) void k_read(const float4* __restrict__ a, floa
     if (s.x + s.y + s.z + s.w == 12345.678f) out[0] = s.x;
 }
 
+// the accumulators are separate named values (an indexed array makes the compiler rotate them through v_accvgpr moves, which
+// then dominate the loop); the loop body is exactly the MFMAs
 template <int KIND>
 __global__ __launch_bounds__(256) void k_mfma(float* __restrict__ out, int iters) {
-    const f16x8 a = {(_Float16)1.0f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)1.5f, (_Float16)1.0f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)1.5f};
-    const f16x8 b = {(_Float16)0.5f, (_Float16)0.5f, (_Float16)0.5f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)0.25f, (_Float16)0.25f, (_Float16)0.25f};
+    f16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(threadIdx.x * 1e-3f + j); b[j] = (_Float16)(0.25f * j); }
     if (KIND == 0) {
-        f32x4 c[8];
-        for (int k = 0; k < 8; ++k) c[k] = f32x4{0, 0, 0, 0};
-        for (int i = 0; i < iters; ++i)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) c[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c[k], 0, 0, 0);
-        float s = 0;
-        for (int k = 0; k < 8; ++k) s += c[k][0];
+        f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+        for (int i = 0; i < iters; ++i) {
+#define M16(c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+            M16(c0) M16(c1) M16(c2) M16(c3) M16(c4) M16(c5) M16(c6) M16(c7)
+        }
+        const float s = c0[0] + c1[0] + c2[0] + c3[0] + c4[0] + c5[0] + c6[0] + c7[0];
         if (s == 1.2345f) out[threadIdx.x] = s;
     } else if (KIND == 1) {
-        f32x16 c[4];
-        for (int k = 0; k < 4; ++k) for (int j = 0; j < 16; ++j) c[k][j] = 0;
-        for (int i = 0; i < iters; ++i)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) c[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[k], 0, 0, 0);
-        float s = 0;
-        for (int k = 0; k < 4; ++k) s += c[k][0];
+        f32x16 c0, c1, c2, c3;
+        for (int j = 0; j < 16; ++j) { c0[j] = 0; c1[j] = 0; c2[j] = 0; c3[j] = 0; }
+        for (int i = 0; i < iters; ++i) {
+#define M32(c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+            M32(c0) M32(c1) M32(c2) M32(c3)
+        }
+        const float s = c0[0] + c1[0] + c2[0] + c3[0];
         if (s == 1.2345f) out[threadIdx.x] = s;
     } else {
-        f32x4 c[8];
-        for (int k = 0; k < 8; ++k) c[k] = f32x4{0, 0, 0, 0};
-        for (int i = 0; i < iters; ++i)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) c[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, 0.5f, c[k], 0, 0, 0);
-        float s = 0;
-        for (int k = 0; k < 8; ++k) s += c[k][0];
+        f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+        const float x = threadIdx.x * 1e-3f, y = 0.5f + threadIdx.x;
+        for (int i = 0; i < iters; ++i) {
+#define M4(c) c = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0);
+            M4(c0) M4(c1) M4(c2) M4(c3) M4(c4) M4(c5) M4(c6) M4(c7)
+        }
+        const float s = c0[0] + c1[0] + c2[0] + c3[0] + c4[0] + c5[0] + c6[0] + c7[0];
         if (s == 1.2345f) out[threadIdx.x] = s;
     }
 }
@@ -83,7 +84,8 @@ int main() {
                2.0 * bytes / best_c / 1e6, (double)bytes / best_r / 1e6);
     }
     const int iters = 20000;
-    const int grid = p.multiProcessorCount * 8;      // 8 workgroups of 4 waves per CU = 8 waves per SIMD
+    for (int wps : {1, 2, 3, 4, 8}) {
+    const int grid = p.multiProcessorCount * wps;      // wps workgroups of 4 waves per CU = wps waves per SIMD
     struct { const char* name; double flop; int kind; int per_iter; } cases[] = {
         {"v_mfma_f32_16x16x32_f16", 2.0 * 16 * 16 * 32, 0, 8}, {"v_mfma_f32_32x32x16_f16", 2.0 * 32 * 32 * 16, 1, 4}, {"v_mfma_f32_16x16x4_f32", 2.0 * 16 * 16 * 4, 2, 8}};
     for (auto& c : cases) {
@@ -97,7 +99,9 @@ int main() {
             if (rep && ms < best) best = ms;
         }
         const double total = (double)grid * 4 * iters * c.per_iter * c.flop;
-        printf("MFMA %-26s %8.1f TFLOP/s dense (%d waves/SIMD, %d independent accumulators)\n", c.name, total / best / 1e9, 8, c.per_iter);
+        printf("MFMA %-26s %8.1f TFLOP/s dense (%d waves/SIMD, %d independent accumulators)  = %.1f cycles per MFMA per SIMD at 2.4 GHz\n", c.name,
+               total / best / 1e9, wps, c.per_iter, best * 1e-3 * 2.4e9 / ((double)wps * iters * c.per_iter));
+    }
     }
     return 0;
 }
