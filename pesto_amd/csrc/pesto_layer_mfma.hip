@@ -39,29 +39,31 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 // exact in fp32). Two 16-feature blocks (4 + 4 values of this lane) form the 8 k-values one lane feeds to
 // v_mfma_f32_16x16x32_f16. Three MFMAs (hi*hi, lo*hi, hi*lo) then reproduce the fp32 product to ~2^-21.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// NOTE: the residual could be one v_fma_mixlo/mixhi_f16 per element (f16(x - hi) in a single mixed-precision fma), but the
-// compiler only emits those from inline asm, and inline asm is invisible to the MFMA hazard recogniser: a register it
-// overwrites may still be read as SrcC by an in-flight MFMA (seen as rare, timing-dependent corruption in a node-kernel
-// variant). Plain convert / subtract / convert costs 3 more VALU per pair and is hazard-checked.
+// The residual lo = rn16(x - hi) is ONE mixed-precision fma per element (v_fma_mixlo_f16 / v_fma_mixhi_f16: f16(f16(hi) * -1 + x),
+// the same single rounding since x - hi is exact in fp32): 12 VALU per 8 values instead of 20 for convert-back / subtract /
+// convert. The compiler only selects the mix forms when the multiplier is not a foldable constant (fma(h, -1, x) is
+// canonicalised to a subtract first), hence the opaque scalar -1. Compiler-generated, so the MFMA hazard recogniser sees the
+// instructions - round 1's inline-asm version of the same idea was invisible to it and corrupted an in-flight SrcC.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
     const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    float m1 = -1.0f;
+    asm("" : "+s"(m1));
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {   // pairs, round to nearest (v_cvt_pk_f16_f32 on gfx950): |x - hi| <= 2^-12 |x|, hi + lo carries 2^-22
         const f32x2 x = {v[j], v[j + 1]};
         const f16x2 h = __builtin_convertvector(x, f16x2);
-        const f32x2 r = x - __builtin_convertvector(h, f32x2);
-        const f16x2 l = __builtin_convertvector(r, f16x2);
         hi[j] = h[0]; hi[j + 1] = h[1];
-        lo[j] = l[0]; lo[j + 1] = l[1];
+        lo[j] = (_Float16)__builtin_fmaf((float)h[0], m1, v[j]);
+        lo[j + 1] = (_Float16)__builtin_fmaf((float)h[1], m1, v[j + 1]);
     }
 }
 // Range guard of the f16-split path. A value beyond +-65504 splits into hi = +-inf, lo = -+inf, and every MFMA output fed by
 // it becomes NaN (inf - inf, or 0 * inf). ELU = med3(x, exp(x) - 1, 0) turns that NaN into 0, i.e. into a silently wrong
 // result, so one register of every accumulator chain is probed BEFORE its ELU: x * 0 + acc stays 0 for finite x and
 // becomes NaN for inf / NaN (one v_fmac_f32). Chains that reach Z or the state without an ELU (keys -> softmax weights,
-// values -> weighted sums, qpm / ppm outputs) carry their NaN to the next node kernel's probes. A wave whose probe ended
+// values -> weighted sums, qpm / ppm outputs) carry their NaN to the next probes downstream. A wave whose probe ended
 // as NaN sets bit 4 of the flags word; the host re-runs the forward on the exact fp32 kernels (PESTO_PRECISION_AUTO) or
 // reports the range error, and the pool kernel turns every logit into NaN - never a plausible wrong number.
 __device__ __forceinline__ void sat_probe(float& acc, float x) { acc = __builtin_fmaf(x, 0.0f, acc); }

@@ -30,7 +30,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][-40:]
+        k = row["Kernel_Name"].split("(")[0][-46:]
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         if row["Counter_Name"] in ("SQ_WAVE_CYCLES", "SQ_INSTS_LDS", "TCC_HIT_sum", "FETCH_SIZE", "WRITE_SIZE"):
             cnt[(k, row["Counter_Name"])] += 1
@@ -48,8 +48,9 @@ tot_f = tot_w = 0.0
 per = {}
 for k in agg:
     if "k_edge" in k or "k_node" in k:
-        calls = 33 if "k_node" in k else 8
         nf = max(cnt.get((k, "FETCH_SIZE"), 1), 1); nw = max(cnt.get((k, "WRITE_SIZE"), 1), 1)
+        n_fwd = max([v for (kk, c), v in cnt.items() if "k_embed" in kk and c == "FETCH_SIZE"] + [1])     # one k_embed launch per forward
+        calls = round(nf / n_fwd)
         f = agg[k].get("FETCH_SIZE", 0.0) / nf * 1024.0     # rocprofv3 reports KiB
         w = agg[k].get("WRITE_SIZE", 0.0) / nw * 1024.0
         per[k.strip()] = {"fetch_bytes_per_dispatch_raw": f, "write_bytes_per_dispatch": w, "dispatches_per_forward": calls}
