@@ -1,6 +1,9 @@
 #!/bin/bash
-# usage: ab.sh tagA tagB ...  -> runs each twice interleaved on the same box
+# A/B of developer builds on ONE box (boxes of the pool differ by several %): profiles/ab.sh [-b BATCH] tagA tagB ...
+# runs bench.py with each pesto_amd/csrc/libpesto_hip_<tag>.so twice, interleaved; results in gpurun_out/ab/<tag>_<rep>.json
+B=8
+if [ "$1" = "-b" ]; then B=$2; shift 2; fi
 mkdir -p gpurun_out/ab
 for rep in 1 2; do for t in "$@"; do
-  PESTO_LIB=$PWD/pesto_amd/csrc/libpesto_hip_$t.so python bench.py --steps 10 --warmup 3 --cpu-budget 0 --no-extras --no-latency --no-check --precision f16_split > gpurun_out/ab/${t}_$rep.json 2>/dev/null
+  PESTO_LIB=$PWD/pesto_amd/csrc/libpesto_hip_$t.so python bench.py --batch $B --steps 10 --warmup 3 --cpu-budget 0 --no-extras --no-latency --no-check --precision f16_split > gpurun_out/ab/${t}_$rep.json 2>/dev/null
 done; done
