@@ -52,20 +52,20 @@ def layer_flops_per_atom(nn):
     return 2.0 * (13696.0 + 36376.0 * nn)
 
 
-def edge_mfma_flops_per_tile(nn):
-    """FLOPs the matrix cores execute per 16-edge tile of the shipped edge kernel: 8 (16 when nn = 8) fp32 16x16x4 MFMAs
-    (1,024 MAC: the centre terms) + 90 f16 16x16x32 MFMAs (8,192 MAC; 3 products of the hi/lo split: 24 for the p_j.r block of
-    layer 1, 18 key networks, 48 value network)."""
-    return ((16 if nn == 8 else 8) * 1024 + 90 * 8192) * 2.0
+def edge_mfma_flops_per_atom(nn):
+    """FLOPs the matrix cores execute per centre atom in the shipped edge kernel. Per 16-edge tile: 8 (16 when nn = 8) fp32 16x16x4
+    MFMAs (1,024 MAC: the centre terms) + 90 f16 16x16x32 MFMAs (8,192 MAC; 3 products of the hi/lo split: 24 for the p_j.r block of
+    layer 1, 18 key networks, 48 value network). Finish phase inside the kernel: 60 f16 MFMAs per 16 centres (qpm 24, ppm 36)."""
+    per_tile = ((16 if nn == 8 else 8) * 1024 + 90 * 8192) * 2.0
+    return nn / 16.0 * per_tile + 60 * 8192 * 2.0 / 16.0
+
+
+NODE_MFMA_FLOPS_PER_ATOM = 189 * 8192 * 2.0 / 16.0      # node kernel (records only): [U|A] 96 + G 72 + nqm 21 f16 MFMAs per 16 atoms
 
 
 def executed_mfma_flops(config, n1):
-    """per forward: edge kernels + node kernel (249 f16 MFMAs per 16 atoms)."""
-    total = 0.0
-    for l in config["sum"]:
-        total += n1 * l["nn"] / 16.0 * edge_mfma_flops_per_tile(l["nn"])
-        total += n1 / 16.0 * 249 * 8192 * 2.0
-    return total
+    """per forward: edge kernels (with their finish phase) + node kernels."""
+    return sum(edge_mfma_flops_per_atom(l["nn"]) + NODE_MFMA_FLOPS_PER_ATOM for l in config["sum"]) * n1
 
 
 def layer_gather_bytes_per_atom(nn):
@@ -353,7 +353,7 @@ def main():
     if dom:
         t_s = dom["avg_launch_ms"] * 1e-3
         b_a = layer_gather_bytes_per_atom(nn_max) * n1
-        f_exec = n1 * nn_max / 16.0 * edge_mfma_flops_per_tile(nn_max)
+        f_exec = n1 * edge_mfma_flops_per_atom(nn_max)
         f_ref = 2.0 * 36376.0 * nn_max * n1
         hbm_frac = b_a / t_s / 1e9 / PEAK_HBM_GBS
         mfma_frac = f_exec / t_s / 1e12 / PEAK_F16_TFLOPS
@@ -365,7 +365,7 @@ def main():
                 traffic = 2.0 * hit[0]["fetch_bytes_per_dispatch_raw"] + hit[0]["write_bytes_per_dispatch"]
         bound = "hbm" if hbm_frac >= mfma_frac else "mfma"
         roofline = {
-            "kernel": f"k_edge<{nn_max}> (dominant: {dom['avg_launch_ms'] * dom['launches_per_forward'] / t_all:.0%} of the layer time)",
+            "kernel": f"k_edge<{nn_max}> incl. its finish phase (dominant: {dom['avg_launch_ms'] * dom['launches_per_forward'] / t_all:.0%} of the layer time)",
             "bound": bound,
             "achieved": b_a / t_s / 1e9 if bound == "hbm" else f_exec / t_s / 1e12,
             "peak": PEAK_HBM_GBS if bound == "hbm" else PEAK_F16_TFLOPS,
@@ -374,11 +374,14 @@ def main():
             "traffic": traffic,
             "avg_launch_ms": dom["avg_launch_ms"], "atoms_per_launch": n1,
             "hbm": {"algorithmic_bytes_per_launch": b_a, "achieved_GBps": b_a / t_s / 1e9, "peak_GBps": PEAK_HBM_GBS, "frac": hbm_frac,
-                    "definition": "SURVEY 8d (A): gather-counted bytes, (1,024 + 532 nn) per atom-layer - every edge counts its "
-                                  "neighbour's 512 B state, 16 B geometry and 4 B id. Most gathers hit L2 / Infinity Cache, so this is a "
-                                  "cache-bandwidth figure priced at the HBM peak; `traffic` is what actually reached the fabric"},
+                    "definition": "SURVEY 8d (A): gather-counted bytes, (1,024 + 532 nn) per atom-layer - own state read + written (the "
+                                  "kernel does both since the finish phase moved into it) and, per edge, the neighbour's 512 B state, 16 B "
+                                  "geometry and 4 B id. Most gathers hit L2 / Infinity Cache, so this is a cache-bandwidth figure priced at "
+                                  "the HBM peak; `traffic` is what actually reached the fabric"},
             "mfma": {"executed_flops_per_launch": f_exec, "achieved_TFLOPs": f_exec / t_s / 1e12, "peak_TFLOPs": PEAK_F16_TFLOPS, "frac": mfma_frac,
-                     "definition": "FLOPs the matrix cores execute (3 products per f16-split GEMM, fp32 accumulate) / dense f16 MFMA peak"},
+                     "definition": "FLOPs the matrix cores execute (3 products per f16-split GEMM, fp32 accumulate) / dense f16 MFMA peak "
+                                   "(spec 2.5 PF; v_mfma_f32_16x16x32_f16 itself tops out at 2.0-2.1 PF on this chip, "
+                                   "profiles/microbench/r02_peaks.txt)"},
             "useful_TFLOPs": f_ref / t_s / 1e12,
             "useful_definition": "reference-formulation FLOPs of the edge part (SURVEY 8d: 2 x 36,376 x nn per atom) / time; the kernel executes "
                                  "fewer (first-layer linearity) on the f16 pipe, so this is NOT a fraction of any peak",

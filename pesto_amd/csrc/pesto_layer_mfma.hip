@@ -539,7 +539,7 @@ __device__ unsigned long long g_phase_cycles[12];
 #define PHASE_DECL() do {} while (0)
 #define PHASE_FLUSH() do {} while (0)
 #endif
-struct EdgeWaveScratch {
+struct alignas(16) EdgeWaveScratch {      // 16-byte multiple: the rows are read / written as float4 (ds_read / ds_write_b128)
     int nb[64];          // neighbour id per row
     float geo[5][64];    // r_hat x, y, z, d per row (SoA); row 4 = 1.0 (k = 3 slot of the centre MFMA's B operand)
     float wts[8][64];    // attention weights [h*4 + part][row]: part 0 scalar, 1..3 the vector chunks
@@ -762,10 +762,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     PHASE_DECL();
     float sat = 0.0f;       // range guard of the f16-split path (sat_probe)
     // the trip count is the same for every wave of a workgroup (FIN: workgroup barriers inside); a wave without a work item idles
-    for (int base = xcd * chunk + jb * WPB * SUBS; base < w_end; base += nbx * WPB * SUBS) {
+    // The SUBS items of a wave: consecutive blocks of WPB items (neighbouring centres share gathered lines in the L1) - except in a
+    // small launch (an XCD's share fits one item per wave): there the second items start behind the first items of ALL workgroups,
+    // so that every workgroup has work before any wave gets a second item
+    const bool small = chunk <= nbx * WPB;
+    const int sstride = small ? nbx * WPB : WPB;
+    for (int base = xcd * chunk + jb * WPB * (small ? 1 : SUBS); base < w_end; base += nbx * WPB * SUBS) {
 #pragma unroll 1
       for (int sub = 0; sub < SUBS; ++sub) {
-      const int work = base + sub * WPB + wave;
+      const int work = base + sub * sstride + wave;
       if (work < w_end) {
         const int c0 = work * A;
         PHASE_INIT();
@@ -1265,7 +1270,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             const int cslot = 16 * tile + fe;   // centre slot of this MFMA column: wave cslot / CPW, staged row cslot % CPW
             const bool cv = cslot < NB;
             const int cw = cv ? cslot / CPW : 0, cr = cv ? cslot % CPW : 0;
-            const int cwork = base + (SUBS > 1 ? cr * WPB : 0) + cw;
+            const int cwork = base + (SUBS > 1 ? cr * sstride : 0) + cw;
             const int ci_raw = cwork * A + (SUBS > 1 ? 0 : cr);
             const bool valid = cv && cwork < w_end && ci_raw < N1;
             const int ci = valid ? ci_raw : 0;
