@@ -762,12 +762,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     PHASE_DECL();
     float sat = 0.0f;       // range guard of the f16-split path (sat_probe)
     // the trip count is the same for every wave of a workgroup (FIN: workgroup barriers inside); a wave without a work item idles
-    // The SUBS items of a wave: consecutive blocks of WPB items (neighbouring centres share gathered lines in the L1) - except in a
-    // small launch (an XCD's share fits one item per wave): there the second items start behind the first items of ALL workgroups,
-    // so that every workgroup has work before any wave gets a second item
-    const bool small = chunk <= nbx * WPB;
-    const int sstride = small ? nbx * WPB : WPB;
-    for (int base = xcd * chunk + jb * WPB * (small ? 1 : SUBS); base < w_end; base += nbx * WPB * SUBS) {
+    // An iteration hands every wave SUBS items. Full iterations: consecutive blocks of WPB items per wave-slot (neighbouring centres
+    // share gathered lines in the L1). The LAST iteration of an XCD's share (fewer items left than slots - in a small launch the only
+    // one): the second items start behind the first items of ALL workgroups, so that the remainder is spread over the workgroups
+    // instead of giving a few of them two items per wave and the rest none. Same trip count for every workgroup of the XCD.
+    for (int it_start = xcd * chunk; it_start < w_end; it_start += nbx * WPB * SUBS) {
+      const bool tail = w_end - it_start < nbx * WPB * SUBS;
+      const int sstride = tail ? nbx * WPB : WPB;
+      const int base = it_start + jb * WPB * (tail ? 1 : SUBS);
 #pragma unroll 1
       for (int sub = 0; sub < SUBS; ++sub) {
       const int work = base + sub * sstride + wave;
