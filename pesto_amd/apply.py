@@ -20,9 +20,34 @@ def _load(path, n0):
     return s, X, q, roa, R
 
 
-def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=24576, workers=8, on_error=print):
+def save_results(results, path):
+    """Bulk result file: what the reference's interfaceome driver keeps in an HDF5 store, ``hf[key] = p.cpu().numpy()`` per
+    structure (interfaceome/apply_model.py:53-79; h5py is not a dependency here). One .npz with the per-structure probability
+    tables stacked along the residue axis: ``keys`` [n] (str), ``offsets`` [n+1] (int64), ``p`` [sum R_i, n_out] (float32) -
+    structure i is p[offsets[i]:offsets[i+1]]. Written atomically (temporary file + rename)."""
+    keys = list(results)
+    tabs = [np.asarray(results[k], dtype=np.float32).reshape(len(results[k]), -1) for k in keys]
+    n_out = tabs[0].shape[1] if tabs else 0
+    offs = np.zeros(len(keys) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([t.shape[0] for t in tabs])
+    p = np.concatenate(tabs, 0) if tabs else np.zeros((0, n_out), np.float32)
+    tmp = path + ".tmp.npz"
+    np.savez_compressed(tmp, keys=np.array(keys, dtype=str), offsets=offs, p=p)
+    os.replace(tmp, path)
+    return path
+
+
+def load_results(path):
+    """{key: p [R, n_out]} from a file written by save_results."""
+    d = np.load(path)
+    offs = d["offsets"]
+    return {str(k): d["p"][offs[i]:offs[i + 1]] for i, k in enumerate(d["keys"])}
+
+
+def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=24576, workers=8, on_error=print, results_path=None):
     """Returns {path: p} with p = sigmoid(z) as numpy [R, n_out] for every structure that could be processed.
     write=True also saves ``path[:-4] + suffix.format(i)`` for each output channel i (apply_model.ipynb:157-166).
+    results_path: also write all probability tables into one bulk result file (save_results), the reference's HDF5 store.
     ``model``: a pesto_amd.Model on a GPU; max_atoms: atoms per launch (about 24k fills an MI355X)."""
     import torch
     n0 = model.config["em"]["N0"]
@@ -68,4 +93,6 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
         flush(group)
         for w in writes:
             w.result()
+    if results_path is not None:
+        save_results(results, results_path)
     return results

@@ -244,3 +244,97 @@ class StructuresDataset:
             s.preprocess(ALL)
             return (s if self.as_structure else s.subunits()), path
         return (s if self.as_structure else s.to_dict()), path
+
+
+# ---------------------------------------------------------------------------------------------- chemical-component CIF
+def _cif_tokens(text):
+    """CIF 1.1 tokens of a data block: whitespace-separated words, 'single' / "double" quoted strings and ;-delimited text
+    fields; # comments are dropped. Quotes end only before whitespace (a ' inside a word, as in atom names like O5', is data)."""
+    out, lines, i = [], text.split("\n"), 0
+    while i < len(lines):
+        line = lines[i]
+        if line.startswith(";"):                       # text field up to the next line that starts with ';'
+            buf = [line[1:]]
+            i += 1
+            while i < len(lines) and not lines[i].startswith(";"):
+                buf.append(lines[i])
+                i += 1
+            out.append(("v", "\n".join(buf).strip()))
+            i += 1
+            continue
+        j, n = 0, len(line)
+        while j < n:
+            c = line[j]
+            if c in " \t\r":
+                j += 1
+            elif c == "#":
+                break
+            elif c in "'\"":
+                k = j + 1
+                while k < n and not (line[k] == c and (k + 1 == n or line[k + 1] in " \t\r")):
+                    k += 1
+                out.append(("v", line[j + 1:k]))
+                j = k + 1
+            else:
+                k = j
+                while k < n and line[k] not in " \t\r":
+                    k += 1
+                out.append(("w", line[j:k]))
+                j = k
+        i += 1
+    return out
+
+
+def _cif_first_block(text):
+    """({tag: value}, {tag: [column values]}) of the FIRST data block: single tag-value pairs and loop_ columns."""
+    toks = _cif_tokens(text)
+    values, loops, i, seen_block = {}, {}, 0, False
+    while i < len(toks):
+        kind, t = toks[i]
+        low = t.lower() if kind == "w" else ""
+        if low.startswith("data_"):
+            if seen_block:
+                break
+            seen_block = True
+            i += 1
+        elif low == "loop_":
+            i += 1
+            tags = []
+            while i < len(toks) and toks[i][0] == "w" and toks[i][1].startswith("_"):
+                tags.append(toks[i][1])
+                i += 1
+            rows = []
+            while i < len(toks) and not (toks[i][0] == "w" and (toks[i][1].startswith("_") or toks[i][1].lower() == "loop_"
+                                                                  or toks[i][1].lower().startswith("data_"))):
+                rows.append(toks[i][1])
+                i += 1
+            if tags:
+                for c, tag in enumerate(tags):
+                    loops[tag] = rows[c::len(tags)]
+        elif kind == "w" and t.startswith("_"):
+            if i + 1 < len(toks):
+                values[t] = toks[i + 1][1]
+            i += 2
+        else:
+            i += 1
+    return values, loops
+
+
+def read_molecule_cif(filepath):
+    """(mol, molid) of a chemical-component dictionary entry (ligand libraries) - what the reference's read_molecule_cif returns
+    (src/structure_io.py:58-93; there the parsing is gemmi's cif.read_file, absent from this image: its find_value / find_loop
+    behaviour on the first data block is restated here): molid = _chem_comp.id; xyz from _chem_comp_atom.model_Cartn_{x,y,z},
+    or - when any of those is '?' - from the pdbx_model_Cartn_*_ideal columns; element = _chem_comp_atom.type_symbol. An entry
+    whose atom table is a single tag-value set instead of a loop (one atom, e.g. an ion) gives xyz = zeros [1,3] and the element in
+    Title case, exactly like the reference."""
+    with open(filepath, "r") as fs:
+        values, loops = _cif_first_block(fs.read())
+    molid = values.get("_chem_comp.id")
+    cols = [loops.get(f"_chem_comp_atom.model_Cartn_{a}", []) for a in "xyz"]
+    if any("?" in c for c in cols):
+        cols = [loops.get(f"_chem_comp_atom.pdbx_model_Cartn_{a}_ideal", []) for a in "xyz"]
+    if len(cols[0]) == 0:
+        mol = {"xyz": np.zeros((1, 3)), "element": np.array([values.get("_chem_comp_atom.type_symbol", "").lower().title()])}
+    else:
+        mol = {"xyz": np.array(cols).T.astype(float), "element": np.array(loops.get("_chem_comp_atom.type_symbol", []))}
+    return mol, molid

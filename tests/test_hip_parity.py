@@ -557,8 +557,12 @@ def test_bulk_apply_model_pdb_in_pdb_out(tmp_path):
     bad = tmp_path / "broken.pdb"
     bad.write_text("ATOM      1  N   ALA A   1      30.837\n")
     errors = []
-    res = apply_model(m, paths[:2] + [str(bad)] + paths[2:], max_atoms=4500, workers=4, on_error=errors.append)
+    from pesto_amd.apply import load_results
+    res = apply_model(m, paths[:2] + [str(bad)] + paths[2:], max_atoms=4500, workers=4, on_error=errors.append,
+                      results_path=str(tmp_path / "bulk.npz"))
     assert set(res) == set(paths) and len(errors) == 1 and "broken.pdb" in errors[0]
+    stored = load_results(str(tmp_path / "bulk.npz"))               # the bulk store (the reference's hf[key] = p)
+    assert set(stored) == set(paths) and all(np.array_equal(stored[k], res[k]) for k in paths)
     for p in paths:
         s = Structure.read_pdb(p).preprocess()
         X, q, roa, R = s.encode(30)

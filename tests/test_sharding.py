@@ -25,9 +25,15 @@ def test_partition_is_balanced_and_complete():
 
 def test_batches_respect_atom_budget():
     sizes = [300, 200, 600, 100, 50]
-    b = sharding.batches([0, 1, 2, 3, 4], sizes, 600)
-    assert b == [[0, 1], [2], [3, 4]]
+    assert sharding.batches([0, 1, 2, 3, 4], sizes, 600, pack=False) == [[0, 1], [2], [3, 4]]      # input order
+    b = sharding.batches([0, 1, 2, 3, 4], sizes, 600)                 # first-fit decreasing: fuller launches
+    assert b == [[0, 1, 3], [2], [4]]
+    assert all(sum(sizes[i] for i in g) <= 600 for g in b) and sorted(i for g in b for i in g) == [0, 1, 2, 3, 4]
     assert sharding.batches([2], sizes, 10) == [[2]]                  # an oversize structure still runs alone
+    rng = np.random.default_rng(0)
+    sz = [int(v) for v in rng.integers(1641, 3053, 53)]
+    packed, seq = sharding.batches(list(range(53)), sz, 24576), sharding.batches(list(range(53)), sz, 24576, pack=False)
+    assert len(packed) <= len(seq) and all(sum(sz[i] for i in g) <= 24576 for g in packed)
 
 
 def _structures():

@@ -152,3 +152,65 @@ def test_writer_number_formatting_equals_python_format():
         want = fmt.format("ATOM", i + 1, "CA", "ALA", "A", i + 1, xyz[i, 0], xyz[i, 1], xyz[i, 2], bf[i], bf[i], "C")
         assert text[i] == want, (i, text[i], want)
     assert text[n] == "TER" and text[n + 1] == "END"
+
+
+def test_read_molecule_cif(tmp_path):
+    """Chemical-component CIF reader (reference src/structure_io.py:58-93, whose parser is gemmi): id, model coordinates, the
+    ideal-coordinate fallback when a model coordinate is '?', quoted atom names, ;-text fields, and the single-atom (no loop) form."""
+    from pesto_amd.structure_io import read_molecule_cif
+    head = """data_ATP
+#
+_chem_comp.id                                    ATP
+_chem_comp.name                                  "ADENOSINE-5'-TRIPHOSPHATE"
+_chem_comp.formula                               'C10 H16 N5 O13 P3'
+_chem_comp.pdbx_synonyms
+;two lines of
+free text with a _tag.like word
+;
+#
+loop_
+_chem_comp_atom.comp_id
+_chem_comp_atom.atom_id
+_chem_comp_atom.type_symbol
+_chem_comp_atom.model_Cartn_x
+_chem_comp_atom.model_Cartn_y
+_chem_comp_atom.model_Cartn_z
+_chem_comp_atom.pdbx_model_Cartn_x_ideal
+_chem_comp_atom.pdbx_model_Cartn_y_ideal
+_chem_comp_atom.pdbx_model_Cartn_z_ideal
+"""
+    rows = """ATP PG    P 1.200  -0.226 -6.850  1.162  -0.221  -5.685
+ATP "O5'" O 2.000  1.0    -3.5    2.1    1.1     -3.4   # a comment
+ATP N1    N -1.5   0.25   7.0     -1.4   0.3     7.1
+#
+loop_
+_chem_comp_bond.comp_id
+_chem_comp_bond.atom_id_1
+ATP PG
+data_SECOND
+_chem_comp.id XXX
+"""
+    p = tmp_path / "atp.cif"
+    p.write_text(head + rows)
+    mol, molid = read_molecule_cif(str(p))
+    assert molid == "ATP" and list(mol["element"]) == ["P", "O", "N"] and mol["xyz"].dtype == np.float64
+    assert np.allclose(mol["xyz"], [[1.2, -0.226, -6.85], [2.0, 1.0, -3.5], [-1.5, 0.25, 7.0]])
+    p.write_text(head + rows.replace("2.000  1.0    -3.5 ", "?      ?      ?    "))       # missing model coordinates -> ideal ones
+    mol, _ = read_molecule_cif(str(p))
+    assert np.allclose(mol["xyz"], [[1.162, -0.221, -5.685], [2.1, 1.1, -3.4], [-1.4, 0.3, 7.1]])
+    ion = tmp_path / "zn.cif"
+    ion.write_text("data_ZN\n_chem_comp.id ZN\n_chem_comp_atom.comp_id ZN\n_chem_comp_atom.atom_id ZN\n_chem_comp_atom.type_symbol ZN\n"
+                   "_chem_comp_atom.model_Cartn_x 0.000\n_chem_comp_atom.model_Cartn_y 0.000\n_chem_comp_atom.model_Cartn_z 0.000\n")
+    mol, molid = read_molecule_cif(str(ion))
+    assert molid == "ZN" and mol["xyz"].shape == (1, 3) and not mol["xyz"].any() and list(mol["element"]) == ["Zn"]
+
+
+def test_bulk_result_file_round_trip(tmp_path):
+    """save_results / load_results: the HDF5-free form of the reference's bulk store hf[key] = p (interfaceome/apply_model.py:53-79)."""
+    from pesto_amd.apply import load_results, save_results
+    rng = np.random.default_rng(4)
+    res = {f"/data/pdb/{k}.pdb": rng.uniform(0, 1, (n, 5)).astype(np.float32) for k, n in (("1abc_A", 122), ("2xyz_B:0", 7), ("q", 1))}
+    path = save_results(res, str(tmp_path / "out.npz"))
+    back = load_results(path)
+    assert list(back) == list(res) and all(np.array_equal(back[k], res[k]) for k in res)
+    assert load_results(save_results({}, str(tmp_path / "empty.npz"))) == {}
