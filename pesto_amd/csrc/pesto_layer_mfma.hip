@@ -5,6 +5,7 @@
 //
 //   k_node16 per ATOM, batched as MFMA GEMMs over 16-atom column tiles (four waves per tile):
 //            (finish) q += qpm(Zq), p += ppm(Zp) of the previous layer, sink row reset            (:147-152, :239-240)
+//                     - on the shipped path this half runs INSIDE the edge kernel (FIN, below); here only for the debug twin
 //            (prep)   the first Linear of the three edge MLPs is linear in its 193 inputs
 //                     [d | X_n(i) | q_j | |p_j| | p_i.r | p_j.r]  (:109-116), so its per-atom pieces are computed
 //                     ONCE per atom instead of once per edge (exact algebra, different summation order):
@@ -14,9 +15,10 @@
 //   k_edge   per EDGE: h1 = ELU(U_i + sum_c r_c G_i[c] + w_d d + A_j + W[:,161:193] (p_j . r))  - centre terms by one K = 4
 //            fp32 MFMA per block, the p_j . r block per edge on f16-split MFMA from the gathered p_j - then layers 2/3 of
 //            eqkm/epkm/evm as MFMA chains held in registers, both softmaxes with DPP reductions, attention-weighted sums
-//            Zq/Zp written per atom.  (:119-144)
+//            Zq/Zp per atom (:119-144). FIN (shipped): the sums stay in LDS; behind a workgroup rendezvous four waves per 16
+//            centres apply qpm / ppm + residual on the matrix cores and write the new state into a ping-pong pair.
 //   Shipped arithmetic: every large GEMM as f16 hi/lo split on v_mfma_f32_16x16x32_f16 (x.w = xh.wh + xl.wh + xh.wl, fp32
-//   accumulate); k_node / PESTO_EDGE_VARIANT=1 keep everything on exact fp32 v_mfma_f32_16x16x4_f32.
+//   accumulate); k_node / k_edge<..., F16 = false> (PESTO_PRECISION_FP32) keep everything on exact fp32 v_mfma_f32_16x16x4_f32.
 //
 // MFMA conventions (16x16x4 f32): lane l = (c = l & 15, g = l >> 4).  D[4g + r][c] is register r of lane l.
 // Operands chain without shuffles: a D tile of features (rows 16fb + 4g + r) x edges (cols c) is fed back as the
