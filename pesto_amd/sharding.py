@@ -69,7 +69,7 @@ def _skippable():
     return (PestoError, ValueError)
 
 
-def forward_local(forward_fn, structures, indices, max_atoms=32768):
+def forward_local(forward_fn, structures, indices, max_atoms=24576):
     """Run ``forward_fn(X, ids_topk, q, M) -> z`` (or a pesto_amd.Model) over this rank's structures, collating several per launch.
     ``structures[i] = (X, ids_topk0, q, M)`` with the per-structure contract of pesto_amd.topology.
     Returns {index: z_i (numpy [R_i, n_out])}.  With a Model the launches use PESTO_BATCH_INDEPENDENT: every structure gets
@@ -169,7 +169,7 @@ def gather_results(local, n_total, n_out, group=None, device=None):
     return out
 
 
-def forward_sharded(forward_fn, structures, n_out, max_atoms=32768, group=None, device=None):
+def forward_sharded(forward_fn, structures, n_out, max_atoms=24576, group=None, device=None):
     """Shard ``structures`` over the ranks of the (already initialised) process group, run them, gather all results
     on every rank.  Single-process (no process group): runs everything locally."""
     import torch.distributed as dist
