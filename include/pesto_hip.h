@@ -118,7 +118,7 @@ int pesto_forward_structures(pesto_model* m, int64_t N, int64_t R, int32_t k, in
  * X + f*x_frame_stride + i*x_atom_stride (strides in floats, xyz contiguous; the reference's [N, frames, 3] trajectory
  * tensor is x_frame_stride = 3, x_atom_stride = 3*frames). z_out is [n_frames, R, n_out]. Results are those of n_frames
  * separate pesto_forward calls (per-frame max(D) and wrap-around, src/model_operations.py:8-12), but frames_per_launch
- * frames (0 = choose: about 32k atoms) run as ONE batch through every kernel. Pointer/stream rules as pesto_forward. */
+ * frames (0 = choose: about 24.6k atoms, four full rounds of the layer kernels) run as ONE batch through every kernel. Pointer/stream rules as pesto_forward. */
 int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_frames,
                          const float* X, int64_t x_frame_stride, int64_t x_atom_stride,
                          const void* ids_topk, int32_t ids_kind, const float* q0, const int32_t* res_of_atom,
