@@ -177,7 +177,7 @@ int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, cons
 /* ---- test hooks ----
  * Debug twins of the shipped kernels, selected per handle (the parity tests run every stage through each of them):
  * layer_kernels 0 = shipped (hybrid first layer; arithmetic per the precision policy), 1 = reference-formulation fp32 VALU
- * kernel (LDS-tiled, no MFMA), 5 = f16-split MFMA with full 2 KB neighbour records (the round-1 design);
+ * kernel (LDS-tiled, no MFMA);
  * knn_brute_force != 0: pesto_knn_collate searches every structure by brute force instead of the cell grid. */
 int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_force);
 

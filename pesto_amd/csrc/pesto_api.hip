@@ -62,7 +62,6 @@ struct pesto_model {
     int precision = PESTO_PRECISION_AUTO;  // pesto_config.precision / pesto_set_precision
     int impl = 2;                          // 2 = MFMA layer (default), 1 = LDS-tiled VALU layer (pesto_debug_select: debug twin)
     int edge_blocks = 512;                 // persistent workgroups of the edge kernel (2 per CU)
-    int fast_variant = 0;                  // kernels of the f16-split path: 0 = hybrid (shipped), 5 = full-record (debug twin)
     bool knn_brute = false;                // pesto_debug_select: brute-force k-NN for every structure
     int64_t n_forward = 0, n_rerun = 0;    // launch sequences run / repeated on the exact fp32 kernels after a range overflow
     // every launch sequence uses the ONE workspace below: sequences on different streams are ordered through this event
@@ -182,7 +181,7 @@ struct FwdArgs {
 int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     const int64_t NT = a.N * a.F, RT = a.R * a.F;
     const int N1 = (int)NT + 1;
-    const int edge_variant = exact ? 1 : m->fast_variant;
+    const int edge_variant = exact ? 1 : 0;
     const size_t n_dmax = a.seg_of_atom ? (size_t)a.n_seg : (size_t)a.F;
     float* q[2] = {m->q_a.as<float>(), m->q_b.as<float>()};
     float* p[2] = {m->p_a.as<float>(), m->p_b.as<float>()};
@@ -383,9 +382,8 @@ int pesto_get_status(const pesto_model* m, int32_t* precision, int64_t* n_forwar
 
 int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_force) {
     if (check_model(m)) return PESTO_ERR_INVALID;
-    if (layer_kernels != 0 && layer_kernels != 1 && layer_kernels != 5) return fail(PESTO_ERR_INVALID, "layer_kernels must be 0, 1 or 5");
+    if (layer_kernels != 0 && layer_kernels != 1) return fail(PESTO_ERR_INVALID, "layer_kernels must be 0 or 1");
     m->impl = layer_kernels == 1 ? 1 : 2;
-    m->fast_variant = layer_kernels == 5 ? 5 : 0;
     m->knn_brute = knn_brute_force != 0;
     return 0;
 }
@@ -768,7 +766,7 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
     const void *q_res = m->q_b.p, *p_res = m->p_b.p;
     if (m->impl == 2) {
         const LayerW* L = &m->img.layers[layer];
-        const int ev = m->precision == PESTO_PRECISION_FP32 ? 1 : m->fast_variant;     // no automatic re-run at stage level
+        const int ev = m->precision == PESTO_PRECISION_FP32 ? 1 : 0;     // no automatic re-run at stage level
         launch_node(st, m->W, nullptr, L, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), ev, err_ptr(m));
         if (ev == 0) {      // shipped path: the finish phase runs inside the edge kernel, new state in the other buffer pair
             launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), nullptr, m->edge_blocks, ev, err_ptr(m),

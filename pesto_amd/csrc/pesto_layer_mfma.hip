@@ -5,12 +5,12 @@
 //
 //   k_node16 per ATOM, batched as MFMA GEMMs over 16-atom column tiles (four waves per tile):
 //            (finish) q += qpm(Zq), p += ppm(Zp) of the previous layer, sink row reset            (:147-152, :239-240)
-//                     - on the shipped path this half runs INSIDE the edge kernel (FIN, below); here only for the debug twin
+//                     - on the shipped path this half runs INSIDE the edge kernel (FIN, below)
 //            (prep)   the first Linear of the three edge MLPs is linear in its 193 inputs
 //                     [d | X_n(i) | q_j | |p_j| | p_i.r | p_j.r]  (:109-116), so its per-atom pieces are computed
 //                     ONCE per atom instead of once per edge (exact algebra, different summation order):
 //                       centre record   U_i = b1 + W[:,1:65] X_n(i),  G_i[c] = W[:,129:161] p_i[c],  Q_i = nqm(X_n(i))
-//                       neighbour record A_j = W[:,65:129] X_n(j)     (shipped "hybrid" path; variants 1 / 5 also store
+//                       neighbour record A_j = W[:,65:129] X_n(j)     (shipped "hybrid" path; the exact fp32 kernels also store
 //                                        C_j[c] = W[:,161:193] p_j[c], a 2 KB record)
 //   k_edge   per EDGE: h1 = ELU(U_i + sum_c r_c G_i[c] + w_d d + A_j + W[:,161:193] (p_j . r))  - centre terms by one K = 4
 //            fp32 MFMA per block, the p_j . r block per edge on f16-split MFMA from the gathered p_j - then layers 2/3 of
@@ -104,6 +104,15 @@ __device__ __forceinline__ f32x4 elu4(f32x4 v) {
     return f32x4{__builtin_amdgcn_fmed3f(v[0], ex[0], 0.0f), __builtin_amdgcn_fmed3f(v[1], ex[1], 0.0f),
                  __builtin_amdgcn_fmed3f(v[2], ex[2], 0.0f), __builtin_amdgcn_fmed3f(v[3], ex[3], 0.0f)};
 #endif
+}
+// log2-domain ELU of the f16-split edge MLPs (pesto_schema.cpp): t = log2(e) x in, log2(e) ELU(x) out - the exp is a bare v_exp_f32
+// and scale + "-1" collapse into one packed fma: 2.5 VALU + 1 transcendental per value instead of 3 + 1
+__device__ __forceinline__ f32x4 elu4s(f32x4 t) {
+    constexpr float C = 1.44269504088896340736f;
+    f32x4 ex = f32x4{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+    ex = ex * C - C;
+    return f32x4{__builtin_amdgcn_fmed3f(t[0], ex[0], 0.0f), __builtin_amdgcn_fmed3f(t[1], ex[1], 0.0f),
+                 __builtin_amdgcn_fmed3f(t[2], ex[2], 0.0f), __builtin_amdgcn_fmed3f(t[3], ex[3], 0.0f)};
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
             const int ob = 4 * role;
             f32x4 a[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = ob < 8 ? ld4(W + wp_.n_b1 + 16 * (ob + j) + 4 * g) : f32x4{0, 0, 0, 0};
+            for (int j = 0; j < 4; ++j) a[j] = ob < 8 ? ld4(W + wp_.n_b1s + 16 * (ob + j) + 4 * g) : f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int kgp = 0; kgp < 2; ++kgp) mfma16_multi<4>(Lua, ob, 2, kgp, lane, xnh[kgp], xnl[kgp], a);
             sat_probe(sat, a[0][0]);
@@ -699,7 +708,7 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
         const f32x4 w4 = ld4(wd + 16 * (fb0 + fb) + 4 * g);
-        h1[fb] = elu4(o.acc[fb] + o.a4[fb] + o.d * w4);
+        h1[fb] = elu4s(o.acc[fb] + o.a4[fb] + o.d * w4);      // every term arrives in the log2 domain
     }
 }
 
@@ -736,6 +745,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     constexpr int TPC = NN >= 16 ? NN / 16 : 1;   // tiles per centre
     static_assert(TI >= TPC && TI % TPC == 0 && A >= 1 && (!PF || TI == 4), "a work item holds whole centres");
     static_assert(!HY || (F16 && !PF), "the hybrid first layer exists on the lean f16-split path only");
+    static_assert(HY == F16, "the f16-split tables are in the log2 domain of the hybrid path (no full-record f16 twin any more)");
     static_assert(!FIN || (HY && A <= 2 && WPB >= 8), "finish phase: at most two staged centres per wave, four waves per 16-centre tile");
     // FIN: work items a wave processes between two finish phases - as many as its two staging rows hold centres (nn = 64: two
     // one-centre items), which halves the number of workgroup rendezvous
@@ -819,8 +829,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     // keys: K = 64 = k-group 0 (eq h2 blocks) + k-group 1 (ep h2 blocks); two accumulators, summed
                     f32x4 kacb = f32x4{0, 0, 0, 0};
                     f16x8 kh[2], kl[2];
-                    split8(elu4(acc2[0]), elu4(acc2[1]), xh[0], xl[0]);
-                    split8(elu4(acc2[2]), elu4(acc2[3]), xh[1], xl[1]);
+                    split8(elu4s(acc2[0]), elu4s(acc2[1]), xh[0], xl[0]);
+                    split8(elu4s(acc2[2]), elu4s(acc2[3]), xh[1], xl[1]);
 #pragma unroll
                     for (int kgp = 0; kgp < 2; ++kgp) {
                         const float* fr = w3k + (size_t)(kgp * 2) * 256 + lane * 4;
@@ -1099,7 +1109,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             __builtin_amdgcn_sched_barrier(0);
             f32x4 h2[4];
 #pragma unroll
-            for (int ml = 0; ml < 4; ++ml) h2[ml] = elu4(acc2[ml]);
+            for (int ml = 0; ml < 4; ++ml) h2[ml] = F16 ? elu4s(acc2[ml]) : elu4(acc2[ml]);
             // V[edge 16t + 4g + r][feature 16fo + e]: edges as rows (A operand = h2), weights as B operand
             f32x4 v[4];
 #pragma unroll
@@ -1400,10 +1410,7 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
     // eight waves = two tiles per iteration; persistent workgroups, at most one per CU (32 per XCD)
     const int pair_chunk = ((tiles + 1) / 2 + 7) / 8;
     const dim3 grid((pair_chunk < 32 ? pair_chunk : 32) * 8), block(NODE_WAVES * 64);
-    if (variant == 0)
-        hipLaunchKernelGGL(k_node16<true>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags);
-    else
-        hipLaunchKernelGGL(k_node16<false>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags);
+    hipLaunchKernelGGL(k_node16<true>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags);
 }
 
 struct EdgeIO {     // per-launch pointers of the edge kernel
@@ -1447,7 +1454,6 @@ static void launch_edge_fin(hipStream_t st, const float* W, const LayerW& lw, in
 // variant 0 (default): hybrid first layer (A_j record + per-edge p_j.r block on MFMA), 12 waves per workgroup (3 per SIMD, one
 //            workgroup per CU), f16-split MFMA; with q_out / p_out the finish phase runs inside (new state -> q_out / p_out)
 // variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch), full 2 KB neighbour records
-// variant 5: the round-1 design - full neighbour records, register-lean VALU first layer, f16-split MFMA, 12 waves per workgroup
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags,
                  const float* q_state, float* q_out, float* p_out) {
@@ -1457,9 +1463,6 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
     const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
     if (variant == 1) {
         launch_edge_t<4, true, false>(st, W, lw, N1, io, max_blocks);
-    } else if (variant == 5) {
-        if (n_work >= 2048) launch_edge_t<12, false, true>(st, W, lw, N1, io, 256);
-        else launch_edge_t<4, false, true>(st, W, lw, N1, io, max_blocks);
     } else if (q_out) {
         if (n_work >= 2048) launch_edge_fin<12, false>(st, W, lw, N1, io, 256);
         else launch_edge_fin<8, true>(st, W, lw, N1, io, 256);

@@ -71,7 +71,15 @@ struct Mat {
     Mat(int r, int c) : rows(r), cols(c), v((size_t)r * c, 0.0f) {}
     float& at(int r, int c) { return v[(size_t)r * cols + c]; }
     float get(int r, int c) const { return (r < rows && c < cols) ? v[(size_t)r * cols + c] : 0.0f; }
+    Mat scaled(float f) const { Mat m = *this; for (float& x : m.v) x *= f; return m; }
 };
+// The f16-split kernels evaluate ELU in the log2 domain: pre-activations arrive multiplied by log2(e), so that exp(x) is a
+// bare v_exp_f32 (2^t) without the scaling multiply, and activations leave multiplied by log2(e) as well:
+//   t = c x,  c ELU(x) = med3(t, c 2^t - c, 0)   (c = log2 e)
+// Per edge MLP  x -> L1 -> ELU -> L2 -> ELU -> L3 : every term of the first pre-activation is scaled by c (U, G, A records,
+// the p_j.r block, the distance column, b1), W2 is unchanged (its input already carries the c) with b2 scaled by c, W3 is divided
+// by c. Only the tables the split kernels read are touched; the exact fp32 kernels keep the reference's numbers.
+constexpr float LOG2E = 1.44269504088896340736f;
 // copy torch weight W[out][in] columns [c0, c0+nc) of rows [0, n_out) into M at (r0, k0)
 void put_block(Mat& M, int r0, int k0, const float* blob, const HostLinear& l, int c0, int nc, int row_lo = 0, int row_n = -1) {
     if (row_n < 0) row_n = l.n_out;
@@ -243,9 +251,11 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
             pad16(img);
             W.e_lds16 = (int32_t)img.size();
             img.insert(img.end(), img.begin() + W.e_lds, img.begin() + W.e_lds + EDGE_LDS_FLOATS);
+            for (int f = 0; f < 128; ++f) { img[W.e_lds16 + EL_B2 + f] *= LOG2E; img[W.e_lds16 + EL_WD + f] *= LOG2E; }    // log2-domain ELU (above)
             Mat Wev2(64, 64), Wv3(64, 64);
             put_block(Wev2, 0, 0, blob, L.evm.l[1], 0, 64);
             put_block(Wv3, 0, 0, blob, L.evm.l[2], 0, 64);
+            Wv3 = Wv3.scaled(1.0f / LOG2E);
             std::vector<float> tmp;
             put_frags_f16(tmp, Wev2, 4, 2);              // 4 out-blocks x 2 k-groups x (hi, lo) x 256 floats = 4096 floats
             std::copy(tmp.begin(), tmp.end(), img.begin() + W.e_lds16 + EL_W2F + 8 * 256);
@@ -261,13 +271,13 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
             put_frags_f16(tmp, Wep2, 2, 1);
             std::copy(tmp.begin(), tmp.end(), img.begin() + W.e_lds16 + EL_W2F);
             tmp.clear();
-            put_frags_f16(tmp, Wk16, 1, 2);
+            put_frags_f16(tmp, Wk16.scaled(1.0f / LOG2E), 1, 2);
             std::copy(tmp.begin(), tmp.end(), img.begin() + W.e_lds16 + EL_W3K);
             // hybrid first layer: the p_j.r block of edge layer 1 (W1[:, 161:193]) applied per edge on the matrix cores
             Mat W1p(128, 32);
             for (int f = 0; f < 128; ++f)
                 for (int c = 0; c < 32; ++c) W1p.at(f, c) = W1.get(f, 161 + c);
-            const int32_t off = put_frags_f16_linear(img, W1p, 8, 1);      // appended right behind the 11600-float image
+            const int32_t off = put_frags_f16_linear(img, W1p.scaled(LOG2E), 8, 1);      // appended right behind the 11600-float image
             if (off != W.e_lds16 + EL_W1P) abort();
         }
         // node kernel: finish (qpm, ppm)
@@ -291,8 +301,11 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
                 for (int c = 0; c < 64; ++c) { Mua.at(f, c) = W1.get(f, 1 + c); Mua.at(128 + f, c) = W1.get(f, 65 + c); }
             for (int f = 0; f < 128; ++f)
                 for (int c = 0; c < 32; ++c) { Mgc.at(f, c) = W1.get(f, 129 + c); Mgc.at(128 + f, c) = W1.get(f, 161 + c); }
-            W.h_ua = put_frags_f16(img, Mua, 16, 2);
-            W.h_gc = put_frags_f16(img, Mgc, 16, 1);
+            W.h_ua = put_frags_f16(img, Mua.scaled(LOG2E), 16, 2);       // records of the split path: log2-domain (above)
+            W.h_gc = put_frags_f16(img, Mgc.scaled(LOG2E), 16, 1);
+            std::vector<float> b1s(b1);
+            for (float& x : b1s) x *= LOG2E;
+            W.n_b1s = put_vec(img, b1s.data(), 128);
             W.n_ua = put_frags(img, Mua, 16, 4);
             W.n_b1 = put_vec(img, b1.data(), 128);
             W.n_gc = put_frags(img, Mgc, 16, 2);

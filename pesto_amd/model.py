@@ -71,8 +71,7 @@ class Model:
         return {"precision": {v: k for k, v in _lib.PRECISIONS.items()}[p.value], "n_forward": a.value, "n_fp32_rerun": b.value}
 
     def debug_select(self, layer_kernels=0, knn_brute_force=False):
-        """Test hook (pesto_debug_select): 0 = shipped kernels, 1 = fp32 VALU reference-formulation kernel, 5 = f16-split with
-        full neighbour records; brute-force k-NN."""
+        """Test hook (pesto_debug_select): 0 = shipped kernels, 1 = fp32 VALU reference-formulation kernel; brute-force k-NN."""
         self._debug = (int(layer_kernels), int(bool(knn_brute_force)))
         if self._handle is not None:
             _lib.check(_lib.load().pesto_debug_select(self._handle, *self._debug))

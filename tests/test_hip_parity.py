@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 
 _IMPL = {"name": "mfma"}
 # layer implementation -> (Model precision, pesto_debug_select layer_kernels)
-_IMPL_ARGS = {"mfma": ("auto", 0), "mfma_records": ("auto", 5), "mfma_exact": ("fp32", 0), "v1": ("auto", 1)}
+_IMPL_ARGS = {"mfma": ("auto", 0), "mfma_exact": ("fp32", 0), "v1": ("auto", 1)}
 
 
-@pytest.fixture(params=["mfma", "mfma_records", "mfma_exact", "v1"])
+@pytest.fixture(params=["mfma", "mfma_exact", "v1"])
 def impl(request):
-    """All layer implementations: the shipped MFMA path (hybrid first layer, big GEMMs on f16-split MFMA, precision "auto"), the
-    round-1 design with full neighbour records (debug twin 5), the same kernels on exact fp32 MFMA (precision "fp32" - also
-    what "auto" falls back to) and the LDS-tiled fp32 VALU kernel (debug twin 1)."""
+    """All layer implementations: the shipped MFMA path (hybrid first layer, big GEMMs on f16-split MFMA, finish phase inside the
+    edge kernel, precision "auto"), the exact fp32 MFMA kernels (precision "fp32" - also what "auto" falls back to) and the
+    LDS-tiled fp32 VALU kernel (debug twin 1)."""
     _IMPL["name"] = request.param
     yield request.param
     _IMPL["name"] = "mfma"
