@@ -180,9 +180,10 @@ def morton_order(X, bits=10):
     return np.argsort(code, kind="stable")
 
 
-def synthetic_structure(n, seed=1, n0=30, atoms_per_res=8, k=64, order="random"):
+def synthetic_structure(n, seed=1, n0=30, atoms_per_res=8, k=64, order="random", topology=True):
     """One synthetic structure with the reference's per-structure contract (before collation):
-    X float32 [n,3]; ids_topk int64 [n, min(k,n)] 0-based; q float32 one-hot [n, n0]; M bool [n, R].
+    X float32 [n,3]; ids_topk int64 [n, min(k,n)] 0-based (None with topology=False: the caller builds it, e.g. on the GPU with
+    Model.knn_collate); q float32 one-hot [n, n0]; M bool [n, R].
     order="random": atoms in generation order (no spatial locality; what the golden fixtures use);
     order="morton": the same cloud with atoms renumbered along a Z-order curve (chain-like locality)."""
     X = synthetic_cloud(n, seed)
@@ -199,4 +200,4 @@ def synthetic_structure(n, seed=1, n0=30, atoms_per_res=8, k=64, order="random")
         q[np.arange(n), 59 + rng.integers(0, 64, n)] = 1.0
     resid = np.arange(n) // atoms_per_res
     M = resid[:, None] == np.unique(resid)[None, :]
-    return X, extract_topology(X, k), q, M
+    return X, (extract_topology(X, k) if topology else None), q, M
