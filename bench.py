@@ -147,7 +147,8 @@ def config4_structures(n_structures, model=None):
         ids = model.knn_collate(np.concatenate([it[0] for it in items]), sizes)          # [sum N, 64], 1-based batch-global
         off = 0
         for it, n in zip(items, sizes):
-            it[1] = ids[off:off + n] - (off + 1)                                          # 0-based within the structure (N >= 64: no padding)
+            it[1] = (ids[off:off + n] - (off + 1)).astype(np.int32)                      # 0-based within the structure (N >= 64: no padding);
+                                                                                          # int32 halves the H2D volume of the tables
             off += n
     return [tuple(it) for it in items], sizes
 
