@@ -321,20 +321,19 @@ __device__ __forceinline__ void mfma16_multi(const float* __restrict__ wf, int m
 // the length of one wave's dependent chain. All weight fragments of both halves (finish 24 KB, [U|A] 64 KB, [G|C] 16/32 KB,
 // nqm 14 KB) are therefore staged into LDS by ONE fill per workgroup (eight waves, one workgroup per CU) that overlaps the
 // state / Z loads - three sequential fill-barrier-compute phases per workgroup cost 27 us per launch, 15 % of a forward.
-// HY (hybrid edge kernel): the neighbour record shrinks to A_j[128] in natural feature order (REC_A floats per atom); the
+// Hybrid edge kernel: the neighbour record is A_j[128] in natural feature order (REC_A floats per atom); the
 // C_j[c] = W[:,161:193] p_j[c] pieces are no longer materialised - the edge kernel applies that block per edge on the matrix
 // cores from the gathered p_j (4x less gather traffic than the 2 KB record, which was the edge kernel's bottleneck).
 constexpr int NODE_WAVES = 8;
 constexpr int NL_FIN = 0, NL_UA = 6144, NL_GC = NL_UA + 16384;
-template <bool HY> constexpr int nl_nq() { return NL_GC + (HY ? 4096 : 8192); }
-template <bool HY> constexpr int node_lds_floats() { return nl_nq<HY>() + 3584; }
+constexpr int NL_NQ = NL_GC + 4096;
+constexpr int NODE_LDS_FLOATS = NL_NQ + 3584;
 
 // Four waves share one 16-atom tile (role = wave & 3) so that the dependent chain a wave walks is ~70 MFMAs, not 249:
 //   finish: role 0 -> qpm (q update), roles 1..3 -> ppm for xyz component role - 1; the updated tile state is exchanged through
 //           LDS (8 KB per tile) behind one workgroup barrier;
-//   prep  : role r -> [U|A] output blocks 4r..4r+3 and [G|C] blocks 2r, 2r+1 (and 8+2r, 9+2r without HY); role 3 also nqm.
+//   prep  : role r -> [U|A] output blocks 4r..4r+3 and G blocks 2r, 2r+1; role 3 also nqm.
 // Workgroups are persistent (eight waves = two tiles per iteration, weights resident in LDS).
-template <bool HY>
 __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
                                                 int N1, float* __restrict__ q_state, float* __restrict__ p_state,
                                                 const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen,
@@ -343,9 +342,9 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
     float sat = 0.0f;
     // wave-uniform by construction; readfirstlane makes it uniform for the compiler too (scalar branches around the MFMA blocks)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), role = wave & 3, slot = wave >> 2;
-    __shared__ __attribute__((aligned(16))) float wl_[node_lds_floats<HY>()];
+    __shared__ __attribute__((aligned(16))) float wl_[NODE_LDS_FLOATS];
     __shared__ __attribute__((aligned(16))) float xch[2][8][256];     // [tile slot][q0 q1 p00 p01 p10 p11 p20 p21][lane][4]
-    {   // one fill: [q0 | q1 | q2 | pp] (contiguous in the image), [U|A], [G|C] (G half only when HY), [n0 | n1 | n2]
+    {   // one fill: [q0 | q1 | q2 | pp] (contiguous in the image), [U|A], G (first half of the [G|C] table), [n0 | n1 | n2]
         auto copy = [&](int dst, const float* src, int n_floats) {
             const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
             f32x4* d4 = reinterpret_cast<f32x4*>(wl_ + dst);
@@ -354,8 +353,8 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
         if (do_finish) copy(NL_FIN, W + wf_.h_q0, 6144);
         if (do_prep) {
             copy(NL_UA, W + wp_.h_ua, 16384);
-            copy(NL_GC, W + wp_.h_gc, HY ? 4096 : 8192);
-            copy(nl_nq<HY>(), W + wp_.h_n0, 3584);
+            copy(NL_GC, W + wp_.h_gc, 4096);
+            copy(NL_NQ, W + wp_.h_n0, 3584);
         }
     }
     // XCD-aware partition of tile PAIRS (same atom ranges per XCD as the edge kernel's work items)
@@ -432,7 +431,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
         }
         __syncthreads();                                     // the next iteration overwrites the exchange buffer
 
-        const float* Lua = wl_ + NL_UA, *Lgc = wl_ + NL_GC, *Lnq = wl_ + nl_nq<HY>();
+        const float* Lua = wl_ + NL_UA, *Lgc = wl_ + NL_GC, *Lnq = wl_ + NL_NQ;
         f32x4 pn[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -446,7 +445,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
         for (int c = 0; c < 3; ++c) split8(p[c][0], p[c][1], ph[c], pl[c]);
 
         float* cen = rec_cen + (size_t)i * REC_CEN;
-        float* nb = rec_nb + (size_t)i * (HY ? REC_A : REC_NB);
+        float* nb = rec_nb + (size_t)i * REC_A;
         {   // [U | A] output blocks 4 role .. 4 role + 3 (U = blocks 0..7 carries b1, A = blocks 8..15)
             const int ob = 4 * role;
             f32x4 a[4];
@@ -459,13 +458,12 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);
-                    else if (HY) st4(nb + (ob + j - 8) * 16 + 4 * g, a[j]);           // A_j[16 fb + 4g + r]
-                    else st4(nb + ((ob + j - 8) * 4 + g) * 16, a[j]);
+                    else st4(nb + (ob + j - 8) * 16 + 4 * g, a[j]);                   // A_j[16 fb + 4g + r]
                 }
             }
         }
-#pragma unroll 1
-        for (int ob = 2 * role; ob < (HY ? 8 : 16); ob += 8) {   // [G | C] blocks 2 role, 2 role + 1 (and + 8 without HY)
+        {   // G blocks 2 role, 2 role + 1
+            const int ob = 2 * role;
             f32x4 a[2][3];
             f16x8 wh[2], wl[2];
 #pragma unroll
@@ -487,10 +485,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (ob < 8) st4(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
-                        else st4(nb + ((ob + j - 8) * 4 + g) * 16 + (1 + c) * 4, a[j][c]);
-                    }
+                    for (int c = 0; c < 3; ++c) st4(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
             }
         }
         if (role == 3) {   // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12                        (:119)
@@ -712,22 +707,8 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
     }
 }
 
-// WPB = waves per workgroup: 4 (two workgroups per CU, 2 waves/SIMD, needs the explicit cross-tile prefetch PF)
-// or 12 / 16 (one workgroup per CU, 3 / 4 waves per SIMD sharing one LDS copy of the layer constants).
-// register-lean first layer of one tile (used when PF == false, i.e. with 3+ waves per SIMD hiding the gather latency):
-// blocks are fetched one ahead and consumed immediately instead of holding all four blocks' operands
-template <int NN>
-__device__ __forceinline__ void l1_tile_lean(int fb0, int lane, int g, const TileCtx& tc, const float* __restrict__ wd, f32x4* h1) {
-    L1Ops cur = l1_fetch<NN>(fb0, lane, g, tc.cenA, tc.cenB, tc.recj);
-#pragma unroll
-    for (int fb = 0; fb < 4; ++fb) {
-        L1Ops nxt = cur;
-        if (fb < 3) nxt = l1_fetch<NN>(fb0 + fb + 1, lane, g, tc.cenA, tc.cenB, tc.recj);
-        h1[fb] = l1_compute<NN>(cur, fb0 + fb, g, tc.bgA, tc.bgB, wd, tc.d, tc.rx, tc.ry, tc.rz);
-        cur = nxt;
-    }
-}
-
+// WPB = waves per workgroup: 4 (exact fp32 path: two workgroups per CU, 2 waves/SIMD, explicit cross-tile prefetch PF)
+// or 12 / 8 (f16-split path: one workgroup per CU, 3 / 2 waves per SIMD sharing one LDS copy of the layer constants).
 // FIN (finish in the edge kernel): the attention sums Z of a centre never leave the CU. Every wave leaves the complete Z rows of
 // its (at most two) centres in its LDS scratch; behind a workgroup barrier four waves per 16 centres apply the output MLPs on
 // the matrix cores - role 0: q += qpm(Zq), roles 1..3: p[c] += ppm(Zp[c]) (model_operations.py:147-152), sink reset (:239-240) -
@@ -904,7 +885,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     keys_of_tile(t, h1);
                 }
             } else {
-                if (HY) {
+                {
                     // software pipeline over the four tiles: the NEXT tile's gathers are issued as soon as this tile's raw loads
                     // have been consumed, and fly during this tile's MFMA / ELU / key-network work
                     TileCtx tcc = tile_ctx<NN, HY>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
@@ -925,14 +906,6 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         l1_tail(hd, 0, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
                         keys_of_tile(t, h1);
                         __builtin_amdgcn_s_setprio(0);
-                    }
-                } else {
-#pragma unroll 1
-                    for (int t = 0; t < TI; ++t) {   // register-lean: rolled loop, operands fetched block by block
-                        const TileCtx tcc = tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
-                        f32x4 h1[4];
-                        l1_tile_lean<NN>(0, lane, g, tcc, sm.w + EL_WD, h1);
-                        keys_of_tile(t, h1);
                     }
                 }
             }
@@ -1038,14 +1011,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                 for (int fbl = 0; fbl < 4; ++fbl)
                     h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
-            } else if (HY) {
+            } else {
                 const L1Raw raw = l1_issue<NN>(4, t, lane, tc, ws, p_state);
                 __builtin_amdgcn_sched_barrier(0);
                 L1Head hd = l1_head<NN>(raw, t, lane, tc, ws);
                 __builtin_amdgcn_s_setprio(1);
                 l1_tail(hd, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
-            } else {
-                l1_tile_lean<NN>(4, lane, g, tc, sm.w + EL_WD, h1);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1410,7 +1381,7 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
     // eight waves = two tiles per iteration; persistent workgroups, at most one per CU (32 per XCD)
     const int pair_chunk = ((tiles + 1) / 2 + 7) / 8;
     const dim3 grid((pair_chunk < 32 ? pair_chunk : 32) * 8), block(NODE_WAVES * 64);
-    hipLaunchKernelGGL(k_node16<true>, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags);
+    hipLaunchKernelGGL(k_node16, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags);
 }
 
 struct EdgeIO {     // per-launch pointers of the edge kernel
@@ -1463,12 +1434,10 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
     const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
     if (variant == 1) {
         launch_edge_t<4, true, false>(st, W, lw, N1, io, max_blocks);
-    } else if (q_out) {
-        if (n_work >= 2048) launch_edge_fin<12, false>(st, W, lw, N1, io, 256);
-        else launch_edge_fin<8, true>(st, W, lw, N1, io, 256);
     } else {
-        if (n_work >= 2048) launch_edge_t<12, false, true, true>(st, W, lw, N1, io, 256);
-        else launch_edge_t<8, false, true, true, true>(st, W, lw, N1, io, 256);   // 63 KB of constants: one workgroup per CU; fine work items
+        // (the finish phase always runs inside the shipped kernel: q_out / p_out are required)
+        if (n_work >= 2048) launch_edge_fin<12, false>(st, W, lw, N1, io, 256);
+        else launch_edge_fin<8, true>(st, W, lw, N1, io, 256);     // 63 KB of constants: one workgroup per CU; fine work items
     }
 }
 
