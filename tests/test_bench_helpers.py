@@ -1,0 +1,45 @@
+"""bench.py's bookkeeping (no GPU): the algorithmic FLOP / byte figures are SURVEY 8d's, the config-4 size histogram is the one
+captured from the reference's pdbs_test/, launch packing stays within the round size, the traffic stamp tracks the kernel sources."""
+import json
+import os
+
+import numpy as np
+
+import bench
+from conftest import ROOT, golden
+from pesto_amd.config import CONFIGS
+
+
+def test_survey_8d_figures():
+    # FLOP(n) = 2 (13,696 + 36,376 n); B(n) = 1,024 + 532 n  per atom-layer
+    assert [bench.layer_flops_per_atom(n) for n in (8, 16, 32, 64)] == [609408.0, 1191424.0, 2355456.0, 4683520.0]
+    assert [bench.layer_gather_bytes_per_atom(n) for n in (8, 16, 32, 64)] == [5280.0, 9536.0, 18048.0, 35072.0]
+    cfg = CONFIGS["i_v4_1"]
+    assert abs(sum(bench.layer_flops_per_atom(l["nn"]) for l in cfg["sum"]) - 70.72e6) < 0.01e6        # 70.72 MFLOP per atom
+    assert sum(bench.layer_gather_bytes_per_atom(l["nn"]) for l in cfg["sum"]) == 543488.0              # 543,488 B per atom
+    # executed MFMA work of the shipped kernels: 99 MFMAs per 16-edge tile (8 fp32 K=4 + 90 f16 K=32) + 60 per 16 centres
+    per_tile = (8 * 1024 + 90 * 8192) * 2.0
+    assert bench.edge_mfma_flops_per_atom(64) == 4 * per_tile + 60 * 8192 * 2.0 / 16.0
+    assert bench.executed_mfma_flops(cfg, 16) > 0
+
+
+def test_config4_histogram_is_the_reference_set():
+    g = golden("pdbs_test_sizes")
+    assert sorted(int(v) for v in g["atoms"]) == sorted(bench.PDBS_TEST_ATOMS)
+    assert len(bench.PDBS_TEST_ATOMS) == 53 and sum(bench.PDBS_TEST_ATOMS) == 132417
+    from pesto_amd import sharding
+    sizes = [bench.PDBS_TEST_ATOMS[i % 53] for i in range(64)]
+    groups = sharding.batches(list(range(64)), sizes, 24576)
+    assert all(sum(sizes[i] for i in grp) <= 24576 for grp in groups) and len(groups) == 7   # 154,518 atoms: 6.3 launches' worth
+    parts = sharding.partition(sizes, 8)
+    loads = [sum(sizes[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) < 1641 and all(len(p) == 8 for p in parts)                # 8 GPUs: balanced to one small chain
+
+
+def test_traffic_file_is_stamped():
+    path = os.path.join(ROOT, "profiles", "traffic_i_v4_1_n3000_b8.json")
+    t = json.load(open(path))
+    assert len(t["source_hash"]) == 16 and any("k_edge<64" in k for k in t["kernel_symbols"])
+    assert len(bench.source_hash()) == 16            # (whether it matches the tree decides if bench.py quotes the file)
+    per = [v for k, v in t["kernels"].items() if "k_edge<64" in k][0]
+    assert per["dispatches_per_forward"] == 8 and per["write_bytes_per_dispatch"] > 0
