@@ -60,11 +60,13 @@ def edge_mfma_flops_per_atom(nn):
     return nn / 16.0 * per_tile + 60 * 8192 * 2.0 / 16.0
 
 
-NODE_MFMA_FLOPS_PER_ATOM = 189 * 8192 * 2.0 / 16.0      # node kernel (records only): [U|A] 96 + G 72 + nqm 21 f16 MFMAs per 16 atoms
+# a layer's records ([U|A] 96 + G 72 + nqm 21 f16 MFMAs per 16 atoms): written by the prepare phase of the PREVIOUS layer's edge launch
+# (layer 0: by the one k_node16 launch of a forward)
+NODE_MFMA_FLOPS_PER_ATOM = 189 * 8192 * 2.0 / 16.0
 
 
 def executed_mfma_flops(config, n1):
-    """per forward: edge kernels (with their finish phase) + node kernels."""
+    """per forward: edge kernels (with their finish phase) + one set of records per layer (node kernel / prepare phases)."""
     return sum(edge_mfma_flops_per_atom(l["nn"]) + NODE_MFMA_FLOPS_PER_ATOM for l in config["sum"]) * n1
 
 
@@ -363,7 +365,10 @@ def main():
     if dom:
         t_s = dom["avg_launch_ms"] * 1e-3
         b_a = layer_gather_bytes_per_atom(nn_max) * n1
-        f_exec = n1 * edge_mfma_flops_per_atom(nn_max)
+        # launches of this kernel that also write the next layer's records (every layer but the last has a successor)
+        n_dom = sum(1 for l in config["sum"] if l["nn"] == nn_max)
+        n_prep = sum(1 for i, l in enumerate(config["sum"]) if l["nn"] == nn_max and i + 1 < len(config["sum"]))
+        f_exec = n1 * (edge_mfma_flops_per_atom(nn_max) + NODE_MFMA_FLOPS_PER_ATOM * n_prep / n_dom)
         f_ref = 2.0 * 36376.0 * nn_max * n1
         hbm_frac = b_a / t_s / 1e9 / PEAK_HBM_GBS
         mfma_frac = f_exec / t_s / 1e12 / PEAK_F16_TFLOPS
@@ -375,7 +380,8 @@ def main():
                 traffic = 2.0 * hit[0]["fetch_bytes_per_dispatch_raw"] + hit[0]["write_bytes_per_dispatch"]
         bound = "hbm" if hbm_frac >= mfma_frac else "mfma"
         roofline = {
-            "kernel": f"k_edge<{nn_max}> incl. its finish phase (dominant: {dom['avg_launch_ms'] * dom['launches_per_forward'] / t_all:.0%} of the layer time)",
+            "kernel": f"k_edge<{nn_max}> = one whole state-update layer: edges, attention, the layer's output MLPs (finish phase) and the next "
+                      f"layer's per-atom records (prepare phase) (dominant: {dom['avg_launch_ms'] * dom['launches_per_forward'] / t_all:.0%} of the layer time)",
             "bound": bound,
             "achieved": b_a / t_s / 1e9 if bound == "hbm" else f_exec / t_s / 1e12,
             "peak": PEAK_HBM_GBS if bound == "hbm" else PEAK_F16_TFLOPS,
@@ -385,8 +391,9 @@ def main():
             "avg_launch_ms": dom["avg_launch_ms"], "atoms_per_launch": n1,
             "hbm": {"algorithmic_bytes_per_launch": b_a, "achieved_GBps": b_a / t_s / 1e9, "peak_GBps": PEAK_HBM_GBS, "frac": hbm_frac,
                     "definition": "SURVEY 8d (A): gather-counted bytes, (1,024 + 532 nn) per atom-layer - own state read + written (the "
-                                  "kernel does both since the finish phase moved into it) and, per edge, the neighbour's 512 B state, 16 B "
-                                  "geometry and 4 B id. Most gathers hit L2 / Infinity Cache, so this is a cache-bandwidth figure priced at "
+                                  "kernel does both) and, per edge, the neighbour's 512 B state, 16 B geometry and 4 B id. The launch is the "
+                                  "whole layer since round 2 (in round 1 a 23-29 us node launch per layer was timed separately and not "
+                                  "counted in this kernel's duration). Most gathers hit L2 / Infinity Cache, so this is a cache-bandwidth figure priced at "
                                   "the HBM peak; `traffic` is what actually reached the fabric"},
             "mfma": {"executed_flops_per_launch": f_exec, "achieved_TFLOPs": f_exec / t_s / 1e12, "peak_TFLOPs": PEAK_F16_TFLOPS, "frac": mfma_frac,
                      "definition": "FLOPs the matrix cores execute (3 products per f16-split GEMM, fp32 accumulate) / dense f16 MFMA peak "

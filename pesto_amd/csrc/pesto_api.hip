@@ -59,6 +59,7 @@ struct pesto_model {
     // workspace (library owns weights + a grow-only workspace; no allocation once warm)
     DevBuf ids_s, geo, q_a, p_a, q_b, p_b, pool_a, seg, z, flags;
     DevBuf rec_nb, rec_cen, zrec;          // MFMA path: per-atom neighbour / centre records and attention sums
+    DevBuf rec_nb2;                        // second neighbour-record buffer: an edge launch writes the next layer's records while its own are read
     int precision = PESTO_PRECISION_AUTO;  // pesto_config.precision / pesto_set_precision
     int impl = 2;                          // 2 = MFMA layer (default), 1 = LDS-tiled VALU layer (pesto_debug_select: debug twin)
     int edge_blocks = 512;                 // persistent workgroups of the edge kernel (2 per CU)
@@ -94,7 +95,7 @@ namespace {
 size_t ws_bytes(int64_t N, int64_t R) {
     const size_t N1 = (size_t)N + 1;
     return N1 * KMAX * 4 + N1 * KMAX * 16 + 2 * (N1 * S * 4 + N1 * 96 * 4) + (size_t)N * 8 * 4 + (size_t)R * 8 + (size_t)R * 32 * 4 + 64 +
-           N1 * (REC_NB + REC_CEN + REC_Z) * 4;
+           N1 * (REC_NB + REC_A + REC_CEN + REC_Z) * 4;
 }
 
 int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
@@ -113,6 +114,7 @@ int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
     if (m->impl == 2) {
         rc |= m->rec_nb.ensure(N1 * REC_NB * sizeof(float));
         rc |= m->rec_cen.ensure(N1 * REC_CEN * sizeof(float));
+        rc |= m->rec_nb2.ensure(N1 * REC_A * sizeof(float));
         rc |= m->zrec.ensure(N1 * REC_Z * sizeof(float));
     }
     return rc ? fail(PESTO_ERR_NOMEM, "device workspace allocation failed for N=%lld R=%lld", (long long)N, (long long)R) : 0;
@@ -217,15 +219,19 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     };
     auto nn_class = [](int nn) { return nn == 8 ? 1 : nn == 16 ? 2 : nn == 32 ? 3 : 4; };
     if (m->impl == 2 && edge_variant == 0) {
-        // shipped path, per layer: node kernel (records of layer l from the current state), edge kernel with the finish phase
-        // inside (new state into the other half of the ping-pong pair)
-        for (int l = 0; l < m->cfg.n_layers; ++l) {
-            HIP_TRY(mark(0));
-            launch_node(st, m->W, nullptr, &m->img.layers[l], N1, q[cur], p[cur], m->zrec.as<float>(), m->rec_nb.as<float>(),
-                        m->rec_cen.as<float>(), edge_variant, err_ptr(m));
+        // shipped path: ONE node launch (the first layer's records), then one edge launch per layer - edges and attention, the layer's
+        // output MLPs (finish phase: new state into the other half of the ping-pong pair) and the NEXT layer's records (prepare phase).
+        // Neighbour records (gathered by every workgroup) ping-pong; the centre records are rewritten in place (only the wave that
+        // owns a centre reads its record, before the same workgroup iteration writes the next layer's).
+        float* rnb[2] = {m->rec_nb.as<float>(), m->rec_nb2.as<float>()};
+        float* rcen = m->rec_cen.as<float>();
+        const int L = m->cfg.n_layers;
+        HIP_TRY(mark(0));
+        launch_node(st, m->W, nullptr, &m->img.layers[0], N1, q[0], p[0], m->zrec.as<float>(), rnb[0], rcen, edge_variant, err_ptr(m));
+        for (int l = 0; l < L; ++l) {
             HIP_TRY(mark(nn_class(m->cfg.nn[l])));
-            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(),
-                        m->rec_cen.as<float>(), p[cur], nullptr, m->edge_blocks, edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1]);
+            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), rnb[cur], rcen, p[cur], nullptr, m->edge_blocks,
+                        edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1], l + 1 < L ? &m->img.layers[l + 1] : nullptr, rnb[cur ^ 1], rcen);
             cur ^= 1;
         }
         HIP_TRY(mark(-1));
@@ -253,7 +259,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     }
     if (m->timing) {
         HIP_TRY(hipEventRecord(m->ev[2], st));
-        m->n_layer_launches = m->impl != 2 ? m->cfg.n_layers : edge_variant == 0 ? 2 * m->cfg.n_layers : 2 * m->cfg.n_layers + 1;
+        m->n_layer_launches = m->impl != 2 ? m->cfg.n_layers : edge_variant == 0 ? m->cfg.n_layers + 1 : 2 * m->cfg.n_layers + 1;
         m->have_timing = true;
     }
     launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)NT, (int)RT, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
@@ -344,7 +350,7 @@ int pesto_destroy(pesto_model* m) {
     for (auto& e : m->kev) if (e) (void)hipEventDestroy(e);
     if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
-                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa, &m->knn_grids, &m->knn_cnt, &m->knn_cur, &m->knn_cell, &m->knn_sorted, &m->col_seg, &m->col_segend})
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->rec_nb2, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa, &m->knn_grids, &m->knn_cnt, &m->knn_cur, &m->knn_cell, &m->knn_sorted, &m->col_seg, &m->col_segend})
         b->release();
     delete m;
     return 0;

@@ -23,9 +23,12 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
                  const float* Z, float* rec_nb, float* rec_cen, int variant, int* flags);
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags,
-                 const float* q_state = nullptr, float* q_out = nullptr, float* p_out = nullptr);
+                 const float* q_state = nullptr, float* q_out = nullptr, float* p_out = nullptr, const LayerW* next = nullptr,
+                 float* rec_nb_out = nullptr, float* rec_cen_out = nullptr);
 // q_out / p_out non-null (variant 0 only): the edge kernel also applies the layer's output MLPs (finish phase) and writes the new
-// state there - p_state / q_state (the old state, still gathered by other workgroups) must be different buffers; Z is not used
+// state there - p_state / q_state (the old state, still gathered by other workgroups) must be different buffers; Z is not used.
+// next non-null: it also writes layer `next`'s records of the new state into rec_nb_out / rec_cen_out (prepare phase; buffers
+// different from rec_nb / rec_cen, which other workgroups still read)
 // k-NN + collate; with use_grid the structures of at least knn_cell_min() atoms are searched through a uniform cell grid
 // (buffers: slots n_struct ints = block of the cell arrays per structure or -1, grids n_struct * knn_grid_struct_bytes(), cell_cnt /
 // cell_cur n_slots * knn_cells_per_struct() ints, cell_of n_total ints, sorted n_total float4), smaller ones by brute force; identical

@@ -538,7 +538,7 @@ __device__ unsigned long long g_phase_cycles[12];
 #define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); phase_acc_[k] += now_ - tmark_; tmark_ = now_; } while (0)
 #define PHASE_INIT() tmark_ = __builtin_readcyclecounter()
 #define PHASE_DECL() unsigned long long tmark_ = 0, phase_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PHASE_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_phase_cycles[k_], phase_acc_[k_]); } while (0)
+#define PHASE_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_phase_cycles[k_], phase_acc_[k_]); } while (0)
 #else
 #define PHASE_MARK(k) do {} while (0)
 #define PHASE_INIT() do {} while (0)
@@ -553,10 +553,18 @@ struct alignas(16) EdgeWaveScratch {      // 16-byte multiple: the rows are read
     float zbuf[2][256];  // Zq | Zp staging per centre (two centres per tile when NN == 8)
     float z3buf[2][2][96];  // [centre sel][h][c*32+s]: sum_e w3[h][e] p_j(e), staged for the final combine
 };
-template <int WPB, bool HY>
+// offsets of the NEXT layer's prepare tables (the [U|A], G and nqm fragments / biases of LayerW): the finishing waves of the edge
+// kernel write that layer's centre / neighbour records right behind the state update (k_node16's prepare half, same arithmetic)
+struct PrepW { int32_t h_ua, h_gc, h_n0, n_b1s, n_bn0, n_bn1, n_bn2; };
+// XCH_FLOATS: tile-state exchange of the prepare phase (FIN kernels): per 16-centre tile [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column][4];
+// the second tile of a twelve-wave workgroup holds 8 centres (24 per iteration) and is stored compactly: 2048 + 1024 floats
+constexpr int XCH_FLOATS = 3072;
+template <int WPB, bool HY, bool XCH = false>
 struct EdgeSmem {
     float w[HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS];
     EdgeWaveScratch ws[WPB];
+    float xch[XCH ? XCH_FLOATS : 4];
+    int xflag[4];        // per tile: roles that have posted their slice (monotone counter, 4 per iteration)
 };
 
 // Operands of the first edge layer for feature block fb of one 16-edge tile, fetched one or two blocks AHEAD of
@@ -717,9 +725,12 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
 template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4, bool FIN = false>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
-                                                 const float* __restrict__ rec_nb, const float* __restrict__ rec_cen,
+                                                 const float* __restrict__ rec_nb, const float* rec_cen,
                                                  const float* __restrict__ p_state, float* __restrict__ Z, int* __restrict__ flags,
-                                                 const float* __restrict__ q_state, float* __restrict__ q_out, float* __restrict__ p_out) {
+                                                 const float* __restrict__ q_state, float* __restrict__ q_out, float* __restrict__ p_out,
+                                                 PrepW lwp, float* __restrict__ rec_nb_out, float* rec_cen_out) {
+    // rec_cen_out may be rec_cen itself: a centre's record is read only by the wave that processes the centre, before the finish phase
+    // of the same workgroup iteration rewrites it (no __restrict__ on the pair); rec_nb is gathered by every workgroup: separate buffers
     // TI = 16-edge tiles per wave work item: 4 (64 edge rows) for full launches; small launches (one structure) use finer
     // items - 1 tile for nn = 8 / 16, 2 for nn = 32 - so that the launch is spread over more waves and CUs (latency)
     constexpr int A = 16 * TI / NN;            // whole centres per work item
@@ -731,16 +742,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     // FIN: work items a wave processes between two finish phases - as many as its two staging rows hold centres (nn = 64: two
     // one-centre items), which halves the number of workgroup rendezvous
     constexpr int SUBS = FIN ? 2 / A : 1;
-    __shared__ EdgeSmem<WPB, HY> sm;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = lane & 15, g = lane >> 4;
+    __shared__ EdgeSmem<WPB, HY, FIN> sm;
+    if (threadIdx.x < 4) sm.xflag[threadIdx.x] = 0;
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
         const f32x4* src = reinterpret_cast<const f32x4*>(W + (F16 ? lw.e_lds16 : lw.e_lds));
         f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
         for (int k = threadIdx.x; k < (HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS) / 4; k += WPB * 64) dst[k] = src[k];
     }
     __syncthreads();
-    EdgeWaveScratch& ws = sm.ws[wave];
     const float* w2f = sm.w + EL_W2F;
     const float* w3k = sm.w + EL_W3K;
     const float* w3v = sm.w + EL_W3V;
@@ -754,12 +763,21 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     const int w_end = min(n_work, (xcd + 1) * chunk);
     PHASE_DECL();
     float sat = 0.0f;       // range guard of the f16-split path (sat_probe)
+    int fin_iter = 0;       // finish phases done (FIN)
     // the trip count is the same for every wave of a workgroup (FIN: workgroup barriers inside); a wave without a work item idles
     // An iteration hands every wave SUBS items. Full iterations: consecutive blocks of WPB items per wave-slot (neighbouring centres
     // share gathered lines in the L1). The LAST iteration of an XCD's share (fewer items left than slots - in a small launch the only
     // one): the second items start behind the first items of ALL workgroups, so that the remainder is spread over the workgroups
     // instead of giving a few of them two items per wave and the rest none. Same trip count for every workgroup of the XCD.
     for (int it_start = xcd * chunk; it_start < w_end; it_start += nbx * WPB * SUBS) {
+      // the lane-derived values of the work loop (indices, LDS addresses, masks) are re-derived per iteration from an opaque copy of the
+      // thread index: as loop invariants they would stay in registers across the finish / prepare phase below, which needs them for
+      // weight fragments (forty registers; the fragments of that phase otherwise spill in front of its rendezvous)
+      int tid_i = threadIdx.x;
+      if (FIN) asm volatile("" : "+v"(tid_i));
+      const int lane = tid_i & 63, wave = tid_i >> 6;
+      const int e = lane & 15, g = lane >> 4;
+      EdgeWaveScratch& ws = sm.ws[wave];
       const bool tail = w_end - it_start < nbx * WPB * SUBS;
       const int sstride = tail ? nbx * WPB : WPB;
       const int base = it_start + jb * WPB * (tail ? 1 : SUBS);
@@ -1236,29 +1254,87 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         // ---- finish phase. Four waves per 16 staged centres; three steps so that the other waves wait as little as possible:
         //   (1) before the barrier: this wave's weight fragments -> registers (one L2 round trip, overlapped with the stragglers);
         //   (2) between two barriers: the staged Z rows -> registers (as f16 hi/lo B operands), old state loads issued;
-        //   (3) behind the second barrier (the LDS rows are free again, the other waves are already in their next work item):
-        //       the MFMA chains and the state update.
+        //   (3) behind the second barrier (the LDS rows are free again): the MFMA chains and the state update.
+        // ---- prepare phase (rec_cen_out != null): the NEXT layer's records of these centres from the state just computed, i.e. the
+        // prepare half of k_node16 with the same arithmetic: [U|A] = W [q | ||p||] (+ b1), G[c] = Wg p[c], Q = nqm([q | ||p||])
+        // (model_operations.py:103-119). The finishing roles post their slice of the new tile state (q, p[0], p[1], p[2]) in LDS;
+        //   role c + 1: G[c] straight from its own slice (no waiting);
+        //   role 0    : Q, after the three p slices have been posted;
+        //   the four waves without a finish role: [U|A] blocks 4j..4j+3 of every tile, after all four slices have been posted.
+        // Every weight fragment of the phase is in registers BEFORE the rendezvous (a load issued behind it queues up after the
+        // gathers of the waves that are already in their next work item); the posts are counted in LDS (xflag), the waiting
+        // waves poll - all of them are resident waves of this workgroup.
         constexpr int CPW = A * SUBS;           // staged centres per wave (1 or 2)
         constexpr int NB = WPB * CPW, NTILE = (NB + 15) / 16;
+        static_assert(!FIN || WPB == 4 * NTILE + 4, "four finishing waves per tile + four waves for the [U|A] blocks");
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // uniform for the compiler too: scalar branches around the role code
+        const bool prep = rec_cen_out != nullptr;
         PHASE_INIT();
-        if (wave_u < 4 * NTILE) {
-            const int tile = wave_u >> 2, role = wave_u & 3;
-            // lane index re-materialised behind an opaque barrier: otherwise the per-lane addresses of this phase (and the weight loads
-            // themselves) are hoisted out of the work loop as loop invariants and spilled - the main loop runs at the 168-VGPR limit
-            int lane_f = lane;
-            asm volatile("" : "+v"(lane_f));
-            const int fe = lane_f & 15, fg = lane_f >> 4;
-            // Every global load of this phase - weight fragments, biases, the OLD state of this column's centre - is issued BEFORE the
-            // rendezvous: behind it a load queues up after the gathers the other waves have issued meanwhile (microseconds under load
-            // per dependent round trip). The centre of a column follows from the work-item arithmetic, no LDS needed.
-            const int cslot = 16 * tile + fe;   // centre slot of this MFMA column: wave cslot / CPW, staged row cslot % CPW
+        // lane index re-materialised behind an opaque barrier: otherwise the per-lane addresses of this phase (and the weight loads
+        // themselves) are hoisted out of the work loop as loop invariants and spilled - the main loop runs at the 168-VGPR limit
+        int lane_f = lane;
+        asm volatile("" : "+v"(lane_f));
+        const int fe = lane_f & 15, fg = lane_f >> 4;
+        // the centre of MFMA column fe of a tile follows from the work-item arithmetic, no LDS needed
+        auto centre_of = [&](int tile, int col, int& cw, int& cr, int& ci, bool& valid) {
+            const int cslot = 16 * tile + col;  // centre slot: wave cslot / CPW, staged row cslot % CPW
             const bool cv = cslot < NB;
-            const int cw = cv ? cslot / CPW : 0, cr = cv ? cslot % CPW : 0;
+            cw = cv ? cslot / CPW : 0; cr = cv ? cslot % CPW : 0;
             const int cwork = base + (SUBS > 1 ? cr * sstride : 0) + cw;
             const int ci_raw = cwork * A + (SUBS > 1 ? 0 : cr);
-            const bool valid = cv && cwork < w_end && ci_raw < N1;
-            const int ci = valid ? ci_raw : 0;
+            valid = cv && cwork < w_end && ci_raw < N1;
+            ci = valid ? ci_raw : 0;
+        };
+        auto ncol_of = [&](int tile) { return (tile == NTILE - 1 && (NB & 15) != 0) ? (NB & 15) : 16; };    // centres of a tile (compact rows)
+        auto post = [&](int tile, int blk, const f32x4* v) {      // this role's slice of the new tile state -> exchange buffer, counted
+            const int ncol = ncol_of(tile);
+            float* xs = sm.xch + tile * 2048;
+            if (fe < ncol) {
+                st4(xs + ((2 * blk) * 4 + fg) * ncol * 4 + fe * 4, v[0]);
+                st4(xs + ((2 * blk + 1) * 4 + fg) * ncol * 4 + fe * 4, v[1]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (LDS executes a wave's operations in order; this is for the compiler)
+            if (lane_f == 0) __hip_atomic_fetch_add(&sm.xflag[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto wait_posts = [&](int tile) {
+            const int target = 4 * fin_iter + 4;
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm.xflag[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+                __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        };
+        // [q | ||p||] of a posted tile as f16 hi/lo B operands (k-group 0 = q, 1 = ||p||)
+        auto node_input = [&](int tile, f16x8* xnh, f16x8* xnl) {
+            const int ncol = ncol_of(tile);
+            const float* xs = sm.xch + tile * 2048;
+            const bool xv = fe < ncol;
+            f32x4 q[2], pn[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x4 p3[3];
+                q[m] = ld4(xs + (m * 4 + fg) * ncol * 4 + fe * 4);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p3[c] = ld4(xs + ((2 + 2 * c + m) * 4 + fg) * ncol * 4 + fe * 4);
+                if (!xv) { q[m] = f32x4{0, 0, 0, 0}; p3[0] = q[m]; p3[1] = q[m]; p3[2] = q[m]; }    // (columns past the tile: not stored)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pn[m][r] = sqrtf(p3[0][r] * p3[0][r] + p3[1][r] * p3[1][r] + p3[2][r] * p3[2][r]);
+            }
+            split8(q[0], q[1], xnh[0], xnl[0]);
+            split8(pn[0], pn[1], xnh[1], xnl[1]);
+        };
+        // acc[m] += W[m-block] x (K = 32 k-group): three products of the hi/lo split; fragments fr[(m, hi|lo)]
+#define PESTO_FIN_MFMA(acc, fr, xh_, xl_)                                                   \
+    {                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xh_, acc[m]);     \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xl_, acc[m]);     \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m + 1], xh_, acc[m]); \
+    }
+        if (wave_u < 4 * NTILE) {
+            const int tile = wave_u >> 2, role = wave_u & 3;
+            // Every global load of the finish - weight fragments, biases, the OLD state of this column's centre - is issued BEFORE the
+            // rendezvous: behind it a load queues up after the gathers the other waves have issued meanwhile (microseconds under load
+            // per dependent round trip).
+            int cw, cr, ci; bool valid;
+            centre_of(tile, fe, cw, cr, ci, valid);
             const float* zr = sm.ws[cw].zbuf[cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
             const float* fb = W + lw.h_q0 + lane_f * 4;     // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
             f16x8 zh[2], zl[2];
@@ -1270,13 +1346,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     split8(a0, a1, zh[kgp], zl[kgp]);
                 }
             };
-            // acc[m] += W[m-block] x (K = 32 k-group): three products of the hi/lo split; fragments fr[(m, hi|lo)]
-#define PESTO_FIN_MFMA(acc, fr, xh_, xl_)                                                   \
-    {                                                                                        \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xh_, acc[m]);     \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xl_, acc[m]);     \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m + 1], xh_, acc[m]); \
-    }
+            float* cen = rec_cen_out + (size_t)ci * REC_CEN;
             f32x4 st[2], h[2];
             if (role == 0) {   // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147, :151)
                 f16x8 w0[2][4], w1[4], w2[4];            // [kgp][(m, hi|lo)], [(m, hi|lo)]
@@ -1304,13 +1374,52 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 PESTO_FIN_MFMA(h, w0[0], zh[0], zl[0])
                 PESTO_FIN_MFMA(h, w0[1], zh[1], zl[1])
                 sat_probe(sat, h[0][0]);
+                // prepare phase: the nqm tables take the registers of w0 and the Z operands (dead now); their round trip overlaps
+                // the rest of the qpm chain - this role has no room for them before the rendezvous
+                __builtin_amdgcn_sched_barrier(0);
+                const float* nq = W + lwp.h_n0 + lane_f * 4;   // fragments n0 [m 2][kgp 2] | n1 [m 2] | n2 [1], (hi, lo) pairs of 256 floats
+                f16x8 n0[2][4], n1[4], n2[2];
+                f32x4 hq[2], tq[2], qq[1];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) { n0[kgp][2 * m] = ld8h(nq + ((m * 2 + kgp) * 2) * 256); n0[kgp][2 * m + 1] = ld8h(nq + ((m * 2 + kgp) * 2 + 1) * 256); }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) n1[f] = ld8h(nq + (8 + f) * 256);
+                n2[0] = ld8h(nq + 12 * 256); n2[1] = ld8h(nq + 13 * 256);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { hq[m] = ld4(W + lwp.n_bn0 + 16 * m + 4 * fg); tq[m] = ld4(W + lwp.n_bn1 + 16 * m + 4 * fg); }
+                qq[0] = ld4(W + lwp.n_bn2 + 4 * fg);
+                __builtin_amdgcn_sched_barrier(0);
                 f16x8 xh, xl;
                 split8(elu4(h[0]), elu4(h[1]), xh, xl);
                 PESTO_FIN_MFMA(b1v, w1, xh, xl)
                 sat_probe(sat, b1v[0][0]);
                 split8(elu4(b1v[0]), elu4(b1v[1]), xh, xl);
                 PESTO_FIN_MFMA(b2v, w2, xh, xl)
-                h[0] = b2v[0]; h[1] = b2v[1];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) st[m] += b2v[m];
+                sat_probe(sat, st[0][0]);          // (unused columns were fed zeros and the sink row's finite state)
+                if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
+                if (valid) { float* dst = q_out + (size_t)ci * S; st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]); }
+                PHASE_MARK(10);
+                if (prep) {
+                    post(tile, 0, st);
+                    wait_posts(tile);
+                    f16x8 xnh[2], xnl[2];
+                    node_input(tile, xnh, xnl);
+                    // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12                                    (:119)
+                    PESTO_FIN_MFMA(hq, n0[0], xnh[0], xnl[0])
+                    PESTO_FIN_MFMA(hq, n0[1], xnh[1], xnl[1])
+                    sat_probe(sat, hq[0][0]);
+                    split8(elu4(hq[0]), elu4(hq[1]), xh, xl);
+                    PESTO_FIN_MFMA(tq, n1, xh, xl)
+                    sat_probe(sat, tq[0][0]);
+                    split8(elu4(tq[0]), elu4(tq[1]), xh, xl);
+                    qq[0] = MFMA16(n2[0], xh, qq[0]); qq[0] = MFMA16(n2[0], xl, qq[0]); qq[0] = MFMA16(n2[1], xh, qq[0]);
+                    sat_probe(sat, qq[0][0]);
+                    if (valid) st4(cen + 512 + 4 * fg, qq[0]);
+                }
             } else {           // ppm: 64 -> 32, no bias, xyz component role - 1             (:148, :152)
                 f16x8 wp[2][4];
 #pragma unroll
@@ -1319,6 +1428,13 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     for (int kgp = 0; kgp < 2; ++kgp) { wp[kgp][2 * m] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2) * 256); wp[kgp][2 * m + 1] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2 + 1) * 256); }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) st[m] = ld4(p_state + (size_t)ci * 96 + (role - 1) * 32 + 16 * m + 4 * fg);
+                // prepare phase: the G fragments (eight output blocks, K = 32), (hi, lo) pairs of 256 floats
+                f16x8 gw[8][2];
+                {
+                    const float* Lgc = W + lwp.h_gc + lane_f * 4;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { gw[j][0] = ld8h(Lgc + (j * 2) * 256); gw[j][1] = ld8h(Lgc + (j * 2 + 1) * 256); }
+                }
                 PHASE_MARK(7);
                 lds_barrier();
                 PHASE_MARK(8);
@@ -1329,24 +1445,95 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 h[0] = f32x4{0, 0, 0, 0}; h[1] = h[0];
                 PESTO_FIN_MFMA(h, wp[0], zh[0], zl[0])
                 PESTO_FIN_MFMA(h, wp[1], zh[1], zl[1])
-            }
-#undef PESTO_FIN_MFMA
 #pragma unroll
-            for (int m = 0; m < 2; ++m) st[m] += h[m];
-            sat_probe(sat, st[0][0]);          // (unused columns were fed zeros and the sink row's finite state)
-            if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
-            if (valid) {
-                float* dst = role == 0 ? q_out + (size_t)ci * S : p_out + (size_t)ci * 96 + (role - 1) * 32;
-                st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]);
+                for (int m = 0; m < 2; ++m) st[m] += h[m];
+                sat_probe(sat, st[0][0]);
+                if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
+                if (valid) { float* dst = p_out + (size_t)ci * 96 + (role - 1) * 32; st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]); }
+                PHASE_MARK(10);
+                if (prep) {
+                    post(tile, role, st);
+                    f16x8 ph, pl;
+                    split8(st[0], st[1], ph, pl);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        f32x4 a[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[4 * half + j][0], ph, a[j]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[4 * half + j][0], pl, a[j]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[4 * half + j][1], ph, a[j]);
+                        sat_probe(sat, a[0][0]);
+                        if (valid) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) st4(cen + (4 * half + j) * 64 + (role - 1) * 16 + 4 * fg, a[j]);
+                        }
+                    }
+                }
             }
             __builtin_amdgcn_s_setprio(0);
-            PHASE_MARK(10);
-        } else {       // waves without a finish role: the two rendezvous only
+            PHASE_MARK(11);
+        } else {       // waves without a finish role: the [U | A] blocks 4j .. 4j+3 of every tile (U = blocks 0..7 carries b1, A = 8..15)
+            const int ob = 4 * (wave_u - 4 * NTILE);
+            f16x8 ua[2][4][2];                    // [kgp][block][hi|lo]
+            f32x4 ub[4];
+            {
+                const float* Lua = W + lwp.h_ua + lane_f * 4;        // [m 16][kgp 2][hi|lo][256]
+#pragma unroll
+                for (int kgp = 0; kgp < 2; ++kgp)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float* fr = Lua + (size_t)(((ob + j) * 2 + kgp) * 2) * 256;
+                        ua[kgp][j][0] = ld8h(fr); ua[kgp][j][1] = ld8h(fr + 256);
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ub[j] = ob < 8 ? ld4(W + lwp.n_b1s + 16 * (ob + j) + 4 * fg) : f32x4{0, 0, 0, 0};
+            }
             lds_barrier();
             PHASE_MARK(8);
             lds_barrier();
             PHASE_MARK(9);
+            if (prep) {
+                __builtin_amdgcn_s_setprio(2);
+#pragma unroll 1
+                for (int tile = 0; tile < NTILE; ++tile) {
+                    int cw, cr, ci; bool valid;
+                    centre_of(tile, fe, cw, cr, ci, valid);
+                    wait_posts(tile);
+                    f16x8 xnh[2], xnl[2];
+                    node_input(tile, xnh, xnl);
+                    f32x4 a[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = ub[j];
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnh[kgp], a[j]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnl[kgp], a[j]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][1], xnh[kgp], a[j]);
+                    }
+                    sat_probe(sat, a[0][0]);
+                    if (valid) {
+                        float* cen = rec_cen_out + (size_t)ci * REC_CEN;
+                        float* nb = rec_nb_out + (size_t)ci * REC_A;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
+                            else st4(nb + (ob + j - 8) * 16 + 4 * fg, a[j]);                   // A_j[16 fb + 4g + r]
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            PHASE_MARK(11);
         }
+#undef PESTO_FIN_MFMA
+        ++fin_iter;
       }
     }
     if (F16) sat_flush(sat, flags);
@@ -1358,10 +1545,10 @@ void debug_print_phase_cycles() {
     unsigned long long h[12];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_cycles), sizeof h) == hipSuccess) {
         const char* names[12] = {"setup", "pass1(keys)", "softmax", "p2:L1+L2", "p2:L3(values)", "p2:accumulate", "p2:finalize", "fin:issue", "fin:barrier1",
-                                 "fin:rows+barrier2", "fin:compute", "-"};
+                                 "fin:rows+barrier2", "fin:compute", "fin:prepare"};
         double tot = 0;
-        for (int k = 0; k < 11; ++k) tot += (double)h[k];
-        for (int k = 0; k < 11; ++k) fprintf(stderr, "[pesto phase] %-16s %6.2f %%  (%llu)\n", names[k], 100.0 * h[k] / tot, h[k]);
+        for (int k = 0; k < 12; ++k) tot += (double)h[k];
+        for (int k = 0; k < 12; ++k) fprintf(stderr, "[pesto phase] %-16s %6.2f %%  (%llu)\n", names[k], 100.0 * h[k] / tot, h[k]);
     }
 #endif
 }
@@ -1387,6 +1574,7 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
 struct EdgeIO {     // per-launch pointers of the edge kernel
     const int* ids_s; const float4* geo; const float* rec_nb; const float* rec_cen; const float* p_state; float* Z; int* flags;
     const float* q_state; float* q_out; float* p_out;      // FIN only: old q state, the other half of the ping-pong pair
+    PrepW prep; float* rec_nb_out; float* rec_cen_out;     // FIN only: the next layer's tables and record buffers (null: no prepare phase)
 };
 
 template <int NN, int WPB, bool PF, bool F16, bool HY, int TI, bool FIN = false>
@@ -1397,7 +1585,7 @@ static void launch_edge_k(hipStream_t st, const float* W, const LayerW& lw, int 
     if (blocks > max_blocks) blocks = max_blocks / 8 * 8;
     if (blocks < 8) blocks = 8;
     hipLaunchKernelGGL((k_edge<NN, WPB, PF, F16, HY, TI, FIN>), dim3(blocks), dim3(WPB * 64), 0, st, W, lw, N1, n_work, io.ids_s, io.geo, io.rec_nb,
-                       io.rec_cen, io.p_state, io.Z, io.flags, io.q_state, io.q_out, io.p_out);
+                       io.rec_cen, io.p_state, io.Z, io.flags, io.q_state, io.q_out, io.p_out, io.prep, io.rec_nb_out, io.rec_cen_out);
 }
 
 // FINE = false: 64-row work items for every nn; FINE = true: the finest work item that still holds whole centres
@@ -1427,8 +1615,10 @@ static void launch_edge_fin(hipStream_t st, const float* W, const LayerW& lw, in
 // variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch), full 2 KB neighbour records
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags,
-                 const float* q_state, float* q_out, float* p_out) {
-    const EdgeIO io{ids_s, geo, rec_nb, rec_cen, p_state, Z, flags, q_state, q_out, p_out};
+                 const float* q_state, float* q_out, float* p_out, const LayerW* next, float* rec_nb_out, float* rec_cen_out) {
+    PrepW pw{};
+    if (next) pw = PrepW{next->h_ua, next->h_gc, next->h_n0, next->n_b1s, next->n_bn0, next->n_bn1, next->n_bn2};
+    const EdgeIO io{ids_s, geo, rec_nb, rec_cen, p_state, Z, flags, q_state, q_out, p_out, pw, next ? rec_nb_out : nullptr, next ? rec_cen_out : nullptr};
     // small launches (one structure, or the nn = 8/16 layers of a small batch) cannot fill 256 twelve-wave workgroups:
     // the same kernel body in smaller workgroups spreads them over more CUs
     const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
@@ -1436,7 +1626,11 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
         launch_edge_t<4, true, false>(st, W, lw, N1, io, max_blocks);
     } else {
         // (the finish phase always runs inside the shipped kernel: q_out / p_out are required)
+        // fine work items (one centre each for nn >= 16): when they outnumber the 2,048 wave slots of eight-wave workgroups, twelve
+        // waves give (almost) every item its own wave instead of handing half of the waves two
+        const int n_fine = lw.nn == 8 ? (N1 + 1) / 2 : N1;
         if (n_work >= 2048) launch_edge_fin<12, false>(st, W, lw, N1, io, 256);
+        else if (n_fine > 2048) launch_edge_fin<12, true>(st, W, lw, N1, io, 256);
         else launch_edge_fin<8, true>(st, W, lw, N1, io, 256);     // 63 KB of constants: one workgroup per CU; fine work items
     }
 }

@@ -78,6 +78,28 @@ def test_stage_pool_decode():
     assert np.abs(z - g["z"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("fixture", ["fwd_i_v4_0_2CUA", "edge_n40", "fwd_i_v4_0_2AYO"])
+def test_prepare_phase_in_the_edge_kernel_equals_the_node_kernel_bitwise(fixture):
+    """The forward runs ONE node launch; every later layer's records come from the prepare phase of the previous edge launch. The
+    staged chain (pesto_stage_layer: node kernel + edge kernel per layer, no prepare phase) must give the same bits: the prepare phase
+    restates k_node16's arithmetic on the state the finish phase has just computed (955 atoms: eight-wave workgroups, one tile per
+    rendezvous; 40: wrap-around rows; 2,810: twelve-wave workgroups at nn = 64, twelve-wave fine items at nn = 16 / 32)."""
+    g = golden(fixture)
+    m = _model("i_v4_0", "mfma")
+    roa = g["res_of_atom"]
+    R = int(roa.max()) + 1
+    ids = g["ids_topk"].astype(np.int32)
+    q0 = onehot(g["q_idx"], 30)
+    z = m.forward_segments(g["X"], ids, q0, roa, R)
+    q = np.concatenate([np.zeros((1, 32), np.float32), m.stage_embed(q0)])
+    p = np.zeros((q.shape[0], 3, 32), np.float32)
+    m.stage_unpack(g["X"], ids)
+    for layer in range(len(CONFIGS["i_v4_0"]["sum"])):
+        q, p = m.stage_layer(layer, q, p)
+    _, _, z_staged = m.stage_pool(q[1:], p[1:], roa, R)
+    assert np.array_equal(z, z_staged)
+
+
 @pytest.mark.parametrize("tag,fixture", [
     ("i_v4_0", "fwd_i_v4_0_2CUA"), ("i_v4_0", "fwd_i_v4_0_2AYO"), ("i_v3_0", "fwd_i_v3_0_2CUA"), ("i_v3_1", "fwd_i_v3_1h_2CUA"),
     ("i_v4_0", "edge_n40"), ("i_v4_0", "edge_batch2"), ("i_v4_0", "edge_coincident"), ("i_v4_0", "edge_single_atom_residue"),
