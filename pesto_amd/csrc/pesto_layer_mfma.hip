@@ -550,7 +550,6 @@ struct alignas(16) EdgeWaveScratch {      // 16-byte multiple: the rows are read
     float geo[5][64];    // r_hat x, y, z, d per row (SoA); row 4 = 1.0 (k = 3 slot of the centre MFMA's B operand)
     float wts[8][64];    // attention weights [h*4 + part][row]: part 0 scalar, 1..3 the vector chunks
     float wsum[8][2];    // per centre: sum over edges of the part-2 weights (multiplies p_i)
-    float zbuf[2][256];  // Zq | Zp staging per centre (two centres per tile when NN == 8)
     float z3buf[2][2][96];  // [centre sel][h][c*32+s]: sum_e w3[h][e] p_j(e), staged for the final combine
 };
 // offsets of the NEXT layer's prepare tables (the [U|A], G and nqm fragments / biases of LayerW): the finishing waves of the edge
@@ -559,13 +558,31 @@ struct PrepW { int32_t h_ua, h_gc, h_n0, n_b1s, n_bn0, n_bn1, n_bn2; };
 // XCH_FLOATS: tile-state exchange of the prepare phase (FIN kernels): per 16-centre tile [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column][4];
 // the second tile of a twelve-wave workgroup holds 8 centres (24 per iteration) and is stored compactly: 2048 + 1024 floats
 constexpr int XCH_FLOATS = 3072;
-template <int WPB, bool HY, bool XCH = false>
+// NE = waves that process work items. NE == WPB: every wave does, the finish / prepare phase runs behind workgroup rendezvous.
+// NE < WPB ("node waves"): the other WPB - NE waves ONLY finish / prepare, fed through LDS queues without any workgroup barrier:
+// two generations of staged Z rows per edge wave and of the 16-centre state exchange.
+constexpr int XF_POST = 0, XF_READY = 2, XF_CONSUMED = 4;      // xflag slots: slices posted per tile | rows staged per generation | generations read
+template <int WPB, bool HY, bool XCH = false, int NE = WPB>
 struct EdgeSmem {
+    static constexpr int GEN = (XCH && NE < WPB) ? 2 : 1;
     float w[HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS];
-    EdgeWaveScratch ws[WPB];
-    float xch[XCH ? XCH_FLOATS : 4];
-    int xflag[4];        // per tile: roles that have posted their slice (monotone counter, 4 per iteration)
+    EdgeWaveScratch ws[NE];
+    float zrows[NE][GEN][2][256];   // Zq | Zp staging per centre: two rows per edge wave (and generation)
+    float xch[XCH ? (NE < WPB ? 2 * 2048 : XCH_FLOATS) : 4];
+    int xflag[8];        // monotone counters (see XF_*)
 };
+// poll an LDS counter of this workgroup (all its waves are resident); SLEEP x 64 cycles between two looks: a polling wave takes issue
+// slots from the waves of its SIMD, so a long expected wait polls rarely
+template <int SLEEP = 1>
+__device__ __forceinline__ void lds_wait_ge(int* flag, int target) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+        __builtin_amdgcn_s_sleep(SLEEP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_signal(int* flag, bool one_lane) {     // count one event behind this wave's LDS traffic
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (one_lane) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // Operands of the first edge layer for feature block fb of one 16-edge tile, fetched one or two blocks AHEAD of
 // their use (explicit software prefetch: with 2 waves per SIMD the gather latency is not hidden otherwise).
@@ -722,7 +739,7 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
 // the matrix cores - role 0: q += qpm(Zq), roles 1..3: p[c] += ppm(Zp[c]) (model_operations.py:147-152), sink reset (:239-240) -
 // with the weight fragments streamed from L2, and write the NEW state into the other half of a ping-pong pair (neighbours'
 // p_j of the old state are still being gathered by other workgroups). The node kernel then only prepares records.
-template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4, bool FIN = false>
+template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4, bool FIN = false, int NE = WPB>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* rec_cen,
@@ -742,8 +759,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     // FIN: work items a wave processes between two finish phases - as many as its two staging rows hold centres (nn = 64: two
     // one-centre items), which halves the number of workgroup rendezvous
     constexpr int SUBS = FIN ? 2 / A : 1;
-    __shared__ EdgeSmem<WPB, HY, FIN> sm;
-    if (threadIdx.x < 4) sm.xflag[threadIdx.x] = 0;
+    constexpr bool NODEW = FIN && NE < WPB;      // node-wave mode: waves NE.. finish / prepare only
+    static_assert(NE == WPB || (FIN && WPB - NE == 4 && NE * A * SUBS == 16), "node waves: four of them, one 16-centre tile per iteration");
+    __shared__ EdgeSmem<WPB, HY, FIN, NE> sm;
+    if (threadIdx.x < 8) sm.xflag[threadIdx.x] = 0;
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
         const f32x4* src = reinterpret_cast<const f32x4*>(W + (F16 ? lw.e_lds16 : lw.e_lds));
         f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
@@ -769,7 +788,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     // share gathered lines in the L1). The LAST iteration of an XCD's share (fewer items left than slots - in a small launch the only
     // one): the second items start behind the first items of ALL workgroups, so that the remainder is spread over the workgroups
     // instead of giving a few of them two items per wave and the rest none. Same trip count for every workgroup of the XCD.
-    for (int it_start = xcd * chunk; it_start < w_end; it_start += nbx * WPB * SUBS) {
+    for (int it_start = xcd * chunk; it_start < w_end; it_start += nbx * NE * SUBS) {
       // the lane-derived values of the work loop (indices, LDS addresses, masks) are re-derived per iteration from an opaque copy of the
       // thread index: as loop invariants they would stay in registers across the finish / prepare phase below, which needs them for
       // weight fragments (forty registers; the fragments of that phase otherwise spill in front of its rendezvous)
@@ -777,14 +796,18 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
       if (FIN) asm volatile("" : "+v"(tid_i));
       const int lane = tid_i & 63, wave = tid_i >> 6;
       const int e = lane & 15, g = lane >> 4;
-      EdgeWaveScratch& ws = sm.ws[wave];
-      const bool tail = w_end - it_start < nbx * WPB * SUBS;
-      const int sstride = tail ? nbx * WPB : WPB;
-      const int base = it_start + jb * WPB * (tail ? 1 : SUBS);
+      const int wslot = (NODEW && wave >= NE) ? 0 : wave;      // (node waves never touch the per-wave scratch)
+      EdgeWaveScratch& ws = sm.ws[wslot];
+      float (*zrow)[256] = sm.zrows[wslot][NODEW ? (fin_iter & 1) : 0];
+      const bool tail = w_end - it_start < nbx * NE * SUBS;
+      const int sstride = tail ? nbx * NE : NE;
+      const int base = it_start + jb * NE * (tail ? 1 : SUBS);
+      // node-wave mode: this generation of staging rows was last used two iterations ago - the node waves must have read it
+      if (NODEW && wave < NE && fin_iter >= 2) lds_wait_ge(&sm.xflag[XF_CONSUMED], 4 * (fin_iter - 1));
 #pragma unroll 1
       for (int sub = 0; sub < SUBS; ++sub) {
       const int work = base + sub * sstride + wave;
-      if (work < w_end) {
+      if (work < w_end && (!NODEW || wave < NE)) {
         const int c0 = work * A;
         PHASE_INIT();
         {   // rows of this work item: lane = row
@@ -1200,7 +1223,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             }
             const int slot0 = (FIN && NN >= 16) ? (SUBS > 1 ? sub : (16 * t) / NN) : 0;     // FIN keeps every centre of the iteration staged
             if (g == 0 || (NN == 8 && g == 2)) {
-                float* zb = ws.zbuf[(NN == 8 && g == 2) ? 1 : slot0];
+                float* zb = zrow[(NN == 8 && g == 2) ? 1 : slot0];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1216,7 +1239,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 const int a = NN == 8 ? 2 * t + sel : (16 * t) / NN;
                 const int i = c0 + a;
                 if (FIN) {   // complete the row in place (every lane touches only its own elements)
-                    float* zb = ws.zbuf[NN == 8 ? sel : slot0];
+                    float* zb = zrow[NN == 8 ? sel : slot0];
                     const int c = lane >> 5, s = lane & 31;
                     const float pi0 = pi_pre[sel][0], pi1 = pi_pre[sel][1];
 #pragma unroll
@@ -1225,7 +1248,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         if (lane < 32) zb[64 + 128 + h * 32 + lane] += ws.wsum[a][h] * pi1 + ws.z3buf[sel][h][64 + lane];
                     }
                 } else if (i < N1) {
-                    const float* zb = ws.zbuf[sel];
+                    const float* zb = zrow[sel];
                     float* zo = Z + (size_t)i * REC_Z;
                     zo[lane] = zb[lane];
                     const int c = lane >> 5, s = lane & 31;
@@ -1250,7 +1273,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         }
       }   // work item
       }   // sub
-      if (FIN) {
+      if (FIN && !NODEW) {
         // ---- finish phase. Four waves per 16 staged centres; three steps so that the other waves wait as little as possible:
         //   (1) before the barrier: this wave's weight fragments -> registers (one L2 round trip, overlapped with the stragglers);
         //   (2) between two barriers: the staged Z rows -> registers (as f16 hi/lo B operands), old state loads issued;
@@ -1266,7 +1289,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         // waves poll - all of them are resident waves of this workgroup.
         constexpr int CPW = A * SUBS;           // staged centres per wave (1 or 2)
         constexpr int NB = WPB * CPW, NTILE = (NB + 15) / 16;
-        static_assert(!FIN || WPB == 4 * NTILE + 4, "four finishing waves per tile + four waves for the [U|A] blocks");
+        static_assert(!FIN || NODEW || WPB == 4 * NTILE + 4, "four finishing waves per tile + four waves for the [U|A] blocks");
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // uniform for the compiler too: scalar branches around the role code
         const bool prep = rec_cen_out != nullptr;
         PHASE_INIT();
@@ -1335,7 +1358,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             // per dependent round trip).
             int cw, cr, ci; bool valid;
             centre_of(tile, fe, cw, cr, ci, valid);
-            const float* zr = sm.ws[cw].zbuf[cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
+            const float* zr = sm.zrows[cw][0][cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
             const float* fb = W + lw.h_q0 + lane_f * 4;     // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
             f16x8 zh[2], zl[2];
             auto rows = [&]() {                 // the staged Z rows of this role as f16 hi/lo B operands (K = 64: two k-groups)
@@ -1535,6 +1558,216 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #undef PESTO_FIN_MFMA
         ++fin_iter;
       }
+      if (NODEW) {
+        // ---- node-wave mode: the same finish + prepare arithmetic, but by four waves that do nothing else, fed through LDS queues.
+        // An edge wave stages the Z rows of its two centres of this iteration in generation (iteration & 1) of its staging rows,
+        // counts itself in XF_READY[generation] and goes straight on to its next items: no rendezvous, no weight fragments, no
+        // record stores (whose acknowledgements the next gathers of the same wave would have to wait for) on the waves that
+        // carry the edge work. Node wave r (role r: 0 = q, c + 1 = p[c]) waits for the eight edge waves, copies its part of the 16
+        // rows to registers, counts itself in XF_CONSUMED (two iterations later the edge waves overwrite the generation), runs its
+        // finish chain, posts its slice of the new tile state (exchange buffer, also two generations), then G[c] (roles 1..3), and
+        // - once all four slices are posted - Q (role 0) and the [U|A] blocks 4r..4r+3.
+        constexpr int CPW = A * SUBS;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const int gen = fin_iter & 1;
+        if (wave_u < NE) {
+            lds_signal(&sm.xflag[XF_READY + gen], lane == 0);
+        } else {
+            const int role = wave_u - NE;
+            const bool prep = rec_cen_out != nullptr;
+            const int fe = lane & 15, fg = lane >> 4;
+            // centre of MFMA column fe: edge wave fe / CPW, its staged row fe % CPW (work-item arithmetic of the loop above)
+            const int cw = fe / CPW, cr = fe % CPW;
+            const int cwork = base + (SUBS > 1 ? cr * sstride : 0) + cw;
+            const int ci_raw = cwork * A + (SUBS > 1 ? 0 : cr);
+            const bool valid = cwork < w_end && ci_raw < N1;
+            const int ci = valid ? ci_raw : 0;
+            const float* zr = sm.zrows[cw][gen][cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
+            const float* fb = W + lw.h_q0 + lane * 4;       // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
+            float* xs = sm.xch + gen * 2048;                // [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column 16][4]
+            float* cen = rec_cen_out + (size_t)ci * REC_CEN;
+            f16x8 zh[2], zl[2];
+            auto rows = [&]() {                 // wait for the eight edge waves, then this role's part of the 16 rows as hi/lo B operands
+                lds_wait_ge<16>(&sm.xflag[XF_READY + gen], NE * ((fin_iter >> 1) + 1));
+#pragma unroll
+                for (int kgp = 0; kgp < 2; ++kgp) {
+                    f32x4 a0 = ld4(zr + 32 * kgp + 4 * fg), a1 = ld4(zr + 32 * kgp + 16 + 4 * fg);
+                    if (!valid) { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }     // unused columns: no stale LDS bits into the range guard
+                    split8(a0, a1, zh[kgp], zl[kgp]);
+                }
+                lds_signal(&sm.xflag[XF_CONSUMED], lane == 0);
+            };
+            auto post = [&](const f32x4* v) {
+                st4(xs + ((2 * role) * 4 + fg) * 64 + fe * 4, v[0]);
+                st4(xs + ((2 * role + 1) * 4 + fg) * 64 + fe * 4, v[1]);
+                lds_signal(&sm.xflag[XF_POST], lane == 0);
+            };
+#define PESTO_FIN_MFMA(acc, fr, xh_, xl_)                                                   \
+    {                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xh_, acc[m]);     \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xl_, acc[m]);     \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m + 1], xh_, acc[m]); \
+    }
+            f32x4 st[2];
+            if (role == 0) {   // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147, :151)
+                f16x8 w0[2][4], w1[4], w2[4];            // [kgp][(m, hi|lo)], [(m, hi|lo)]
+                f32x4 h[2], b1v[2], b2v[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) { w0[kgp][2 * m] = ld8h(fb + ((m * 2 + kgp) * 2) * 256); w0[kgp][2 * m + 1] = ld8h(fb + ((m * 2 + kgp) * 2 + 1) * 256); }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) { w1[f] = ld8h(fb + (8 + f) * 256); w2[f] = ld8h(fb + (12 + f) * 256); }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    h[m] = ld4(W + lw.n_bq0 + 16 * m + 4 * fg); b1v[m] = ld4(W + lw.n_bq1 + 16 * m + 4 * fg); b2v[m] = ld4(W + lw.n_bq2 + 16 * m + 4 * fg);
+                    st[m] = ld4(q_state + (size_t)ci * S + 16 * m + 4 * fg);
+                }
+                rows();
+                PESTO_FIN_MFMA(h, w0[0], zh[0], zl[0])
+                PESTO_FIN_MFMA(h, w0[1], zh[1], zl[1])
+                sat_probe(sat, h[0][0]);
+                f16x8 xh, xl;
+                split8(elu4(h[0]), elu4(h[1]), xh, xl);
+                PESTO_FIN_MFMA(b1v, w1, xh, xl)
+                sat_probe(sat, b1v[0][0]);
+                split8(elu4(b1v[0]), elu4(b1v[1]), xh, xl);
+                PESTO_FIN_MFMA(b2v, w2, xh, xl)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) st[m] += b2v[m];
+            } else {           // ppm: 64 -> 32, no bias, xyz component role - 1             (:148, :152)
+                f16x8 wp[2][4];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) { wp[kgp][2 * m] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2) * 256); wp[kgp][2 * m + 1] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2 + 1) * 256); }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) st[m] = ld4(p_state + (size_t)ci * 96 + (role - 1) * 32 + 16 * m + 4 * fg);
+                rows();
+                f32x4 h[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+                PESTO_FIN_MFMA(h, wp[0], zh[0], zl[0])
+                PESTO_FIN_MFMA(h, wp[1], zh[1], zl[1])
+#pragma unroll
+                for (int m = 0; m < 2; ++m) st[m] += h[m];
+            }
+            sat_probe(sat, st[0][0]);          // (unused columns were fed zeros and the sink row's finite state)
+            if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
+            if (valid) {
+                float* dst = role == 0 ? q_out + (size_t)ci * S : p_out + (size_t)ci * 96 + (role - 1) * 32;
+                st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]);
+            }
+            if (prep) {
+                // ---- the NEXT layer's records of these 16 centres (k_node16's prepare half, same arithmetic: model_operations.py:103-119)
+                post(st);
+                if (role != 0) {   // G[c] blocks 0..7 straight from the own slice p[c], c = role - 1
+                    f16x8 ph, pl;
+                    split8(st[0], st[1], ph, pl);
+                    const float* Lgc = W + lwp.h_gc + lane * 4;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        f16x8 gw[4][2];
+                        f32x4 a[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { gw[j][0] = ld8h(Lgc + ((4 * half + j) * 2) * 256); gw[j][1] = ld8h(Lgc + ((4 * half + j) * 2 + 1) * 256); a[j] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[j][0], ph, a[j]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[j][0], pl, a[j]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[j][1], ph, a[j]);
+                        sat_probe(sat, a[0][0]);
+                        if (valid) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) st4(cen + (4 * half + j) * 64 + (role - 1) * 16 + 4 * fg, a[j]);
+                        }
+                    }
+                }
+                // the [U | A] fragments of this wave (blocks 4 role .. 4 role + 3): on their way while the other slices are being posted
+                const int ob = 4 * role;
+                f16x8 ua[2][4][2];                    // [kgp][block][hi|lo]
+                f32x4 ub[4];
+                {
+                    const float* Lua = W + lwp.h_ua + lane * 4;          // [m 16][kgp 2][hi|lo][256]
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float* fr = Lua + (size_t)(((ob + j) * 2 + kgp) * 2) * 256;
+                            ua[kgp][j][0] = ld8h(fr); ua[kgp][j][1] = ld8h(fr + 256);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ub[j] = ob < 8 ? ld4(W + lwp.n_b1s + 16 * (ob + j) + 4 * fg) : f32x4{0, 0, 0, 0};
+                }
+                lds_wait_ge(&sm.xflag[XF_POST], 4 * fin_iter + 4);
+                f16x8 xnh[2], xnl[2];
+                {   // [q | ||p||] of the tile as f16 hi/lo B operands (k-group 0 = q, 1 = ||p||)
+                    f32x4 q[2], pn[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        f32x4 p3[3];
+                        q[m] = ld4(xs + (m * 4 + fg) * 64 + fe * 4);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) p3[c] = ld4(xs + ((2 + 2 * c + m) * 4 + fg) * 64 + fe * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pn[m][r] = sqrtf(p3[0][r] * p3[0][r] + p3[1][r] * p3[1][r] + p3[2][r] * p3[2][r]);
+                    }
+                    split8(q[0], q[1], xnh[0], xnl[0]);
+                    split8(pn[0], pn[1], xnh[1], xnl[1]);
+                }
+                {
+                    f32x4 a[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = ub[j];
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnh[kgp], a[j]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnl[kgp], a[j]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][1], xnh[kgp], a[j]);
+                    }
+                    sat_probe(sat, a[0][0]);
+                    if (valid) {
+                        float* nb = rec_nb_out + (size_t)ci * REC_A;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
+                            else st4(nb + (ob + j - 8) * 16 + 4 * fg, a[j]);                   // A_j[16 fb + 4g + r]
+                        }
+                    }
+                }
+                if (role == 0) {   // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12                        (:119)
+                    const float* nq = W + lwp.h_n0 + lane * 4;     // fragments n0 [m 2][kgp 2] | n1 [m 2] | n2 [1], (hi, lo) pairs of 256 floats
+                    f16x8 n0[2][4], n1[4], n2[2];
+                    f32x4 hq[2], tq[2], qq[1];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int kgp = 0; kgp < 2; ++kgp) { n0[kgp][2 * m] = ld8h(nq + ((m * 2 + kgp) * 2) * 256); n0[kgp][2 * m + 1] = ld8h(nq + ((m * 2 + kgp) * 2 + 1) * 256); }
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) n1[f] = ld8h(nq + (8 + f) * 256);
+                    n2[0] = ld8h(nq + 12 * 256); n2[1] = ld8h(nq + 13 * 256);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) { hq[m] = ld4(W + lwp.n_bn0 + 16 * m + 4 * fg); tq[m] = ld4(W + lwp.n_bn1 + 16 * m + 4 * fg); }
+                    qq[0] = ld4(W + lwp.n_bn2 + 4 * fg);
+                    f16x8 xh, xl;
+                    PESTO_FIN_MFMA(hq, n0[0], xnh[0], xnl[0])
+                    PESTO_FIN_MFMA(hq, n0[1], xnh[1], xnl[1])
+                    sat_probe(sat, hq[0][0]);
+                    split8(elu4(hq[0]), elu4(hq[1]), xh, xl);
+                    PESTO_FIN_MFMA(tq, n1, xh, xl)
+                    sat_probe(sat, tq[0][0]);
+                    split8(elu4(tq[0]), elu4(tq[1]), xh, xl);
+                    qq[0] = MFMA16(n2[0], xh, qq[0]); qq[0] = MFMA16(n2[0], xl, qq[0]); qq[0] = MFMA16(n2[1], xh, qq[0]);
+                    sat_probe(sat, qq[0][0]);
+                    if (valid) st4(cen + 512 + 4 * fg, qq[0]);
+                }
+            }
+#undef PESTO_FIN_MFMA
+        }
+        ++fin_iter;
+      }
     }
     if (F16) sat_flush(sat, flags);
     PHASE_FLUSH();
@@ -1577,14 +1810,14 @@ struct EdgeIO {     // per-launch pointers of the edge kernel
     PrepW prep; float* rec_nb_out; float* rec_cen_out;     // FIN only: the next layer's tables and record buffers (null: no prepare phase)
 };
 
-template <int NN, int WPB, bool PF, bool F16, bool HY, int TI, bool FIN = false>
+template <int NN, int WPB, bool PF, bool F16, bool HY, int TI, bool FIN = false, int NE = WPB>
 static void launch_edge_k(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks) {
     constexpr int A = 16 * TI / NN;
     const int n_work = (N1 + A - 1) / A;
-    int blocks = ((n_work + 7) / 8 + WPB - 1) / WPB * 8;   // per-XCD share of the work items, WPB per workgroup, x 8 XCDs
+    int blocks = ((n_work + 7) / 8 + NE - 1) / NE * 8;     // per-XCD share of the work items, NE (item-processing waves) per workgroup, x 8 XCDs
     if (blocks > max_blocks) blocks = max_blocks / 8 * 8;
     if (blocks < 8) blocks = 8;
-    hipLaunchKernelGGL((k_edge<NN, WPB, PF, F16, HY, TI, FIN>), dim3(blocks), dim3(WPB * 64), 0, st, W, lw, N1, n_work, io.ids_s, io.geo, io.rec_nb,
+    hipLaunchKernelGGL((k_edge<NN, WPB, PF, F16, HY, TI, FIN, NE>), dim3(blocks), dim3(WPB * 64), 0, st, W, lw, N1, n_work, io.ids_s, io.geo, io.rec_nb,
                        io.rec_cen, io.p_state, io.Z, io.flags, io.q_state, io.q_out, io.p_out, io.prep, io.rec_nb_out, io.rec_cen_out);
 }
 
@@ -1610,6 +1843,49 @@ static void launch_edge_fin(hipStream_t st, const float* W, const LayerW& lw, in
     }
 }
 
+// Full launches run twelve waves per workgroup in one of two modes:
+//   rendezvous mode - all twelve waves process work items, the finish / prepare phase runs behind workgroup rendezvous;
+//   node-wave mode  - eight waves process work items, four only finish / prepare (no rendezvous).
+// Per item the node-wave mode costs 0.90 / 0.965 / 1.00 / 1.023 of the rendezvous mode at nn = 8 / 16 / 32 / 64 (same-box A/B at 8 x
+// 3,000 atoms, where both modes fill their last round equally: few edges per centre = the phase is a large share of the layer and
+// pays for its own waves; many edges = the four waves are worth more on the edges). The modes also differ in the ROUND they work in
+// (256 workgroups x 12 or 8 waves x items per iteration): the launch takes the mode with the smaller (rounds paid x round size x
+// cost per item) - e.g. one structure of 20,000 atoms pays 4 rounds of 3,072 items at nn = 32 in rendezvous mode, 5 of 2,048 in
+// node-wave mode (171 -> 141 us). Both modes run the same arithmetic in the same order: results do not depend on the choice.
+static double rounds_paid(int n_work, int waves, int subs) {
+    const int chunk = (n_work + 7) / 8;                                   // per-XCD share
+    const int nbx = (chunk + waves - 1) / waves < 32 ? (chunk + waves - 1) / waves : 32;
+    const double round = (double)nbx * waves * subs;                      // items per iteration and XCD
+    const double its = chunk / round;
+    const double full = (double)(long long)its, rest = its - full;
+    // the last, partly filled iteration spreads its items over all workgroups: with two items per wave and iteration it costs half
+    const double tail = rest <= 0.0 ? 0.0 : (subs == 2 && rest <= 0.5) ? 0.5 : 1.0;
+    return (full + tail) * round;
+}
+static bool node_wave_mode(int nn, int n_work) {
+    const int subs = nn == 64 ? 2 : 1;                                     // items per wave and iteration (two staged centres per wave)
+    const double cost = nn == 8 ? 0.90 : nn == 16 ? 0.965 : nn == 32 ? 1.0 : 1.023;
+    return rounds_paid(n_work, 8, subs) * cost < rounds_paid(n_work, 12, subs);
+}
+static void launch_edge_full(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks) {
+    const int a = lw.nn == 64 ? 1 : 2;                                     // centres per 64-row item (nn = 8: one-tile items of two centres)
+    const bool nw = node_wave_mode(lw.nn, (N1 + a - 1) / a);
+    switch (lw.nn) {
+        case 8: if (nw) launch_edge_k<8, 12, false, true, true, 1, true, 8>(st, W, lw, N1, io, max_blocks);
+                else launch_edge_k<8, 12, false, true, true, 1, true>(st, W, lw, N1, io, max_blocks);
+                break;
+        case 16: if (nw) launch_edge_k<16, 12, false, true, true, 2, true, 8>(st, W, lw, N1, io, max_blocks);
+                 else launch_edge_k<16, 12, false, true, true, 2, true>(st, W, lw, N1, io, max_blocks);
+                 break;
+        case 32: if (nw) launch_edge_k<32, 12, false, true, true, 4, true, 8>(st, W, lw, N1, io, max_blocks);
+                 else launch_edge_k<32, 12, false, true, true, 4, true>(st, W, lw, N1, io, max_blocks);
+                 break;
+        default: if (nw) launch_edge_k<64, 12, false, true, true, 4, true, 8>(st, W, lw, N1, io, max_blocks);
+                 else launch_edge_k<64, 12, false, true, true, 4, true>(st, W, lw, N1, io, max_blocks);
+                 break;
+    }
+}
+
 // variant 0 (default): hybrid first layer (A_j record + per-edge p_j.r block on MFMA), 12 waves per workgroup (3 per SIMD, one
 //            workgroup per CU), f16-split MFMA; with q_out / p_out the finish phase runs inside (new state -> q_out / p_out)
 // variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch), full 2 KB neighbour records
@@ -1629,7 +1905,7 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
         // fine work items (one centre each for nn >= 16): when they outnumber the 2,048 wave slots of eight-wave workgroups, twelve
         // waves give (almost) every item its own wave instead of handing half of the waves two
         const int n_fine = lw.nn == 8 ? (N1 + 1) / 2 : N1;
-        if (n_work >= 2048) launch_edge_fin<12, false>(st, W, lw, N1, io, 256);
+        if (n_work >= 2048) launch_edge_full(st, W, lw, N1, io, 256);
         else if (n_fine > 2048) launch_edge_fin<12, true>(st, W, lw, N1, io, 256);
         else launch_edge_fin<8, true>(st, W, lw, N1, io, 256);     // 63 KB of constants: one workgroup per CU; fine work items
     }
