@@ -196,10 +196,8 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     }
     HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
     HIP_TRY(hipMemsetAsync(m->dmax.p, 0, n_dmax * 4, st));
-    HIP_TRY(hipMemsetAsync(q[0], 0, S * sizeof(float), st));                       // sink row of q (model_operations.py:17)
-    HIP_TRY(hipMemsetAsync(p[0], 0, (size_t)N1 * 96 * sizeof(float), st));         // p0 = zeros (model.py:37)
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[0], st));
-    launch_embed(st, m->W, m->img.model.em, (int)NT, (int)a.N, m->cfg.n0, a.q0, q[0]);
+    launch_embed(st, m->W, m->img.model.em, (int)NT, (int)a.N, m->cfg.n0, a.q0, q[0], p[0]);     // also p0 = zeros and the sink rows (model.py:37, model_operations.py:17)
     launch_unpack(st, (int)a.N, (int)a.F, a.k, a.X, a.xs_frame, a.xs_atom, a.ids, a.ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(),
                   dmax_ptr(m), err_ptr(m), a.seg_of_atom, a.seg_end);
     if (a.F > 1) launch_expand_roa(st, (int)a.N, (int)a.R, (int)a.F, a.roa, m->roa_f.as<int>(), err_ptr(m));

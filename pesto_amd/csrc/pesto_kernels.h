@@ -7,7 +7,8 @@
 namespace pesto {
 
 // N atoms in the batch; q0 has nq rows used with period nq (nq = N, or the frame length of a trajectory batch)
-void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state);
+// p_zero (optional): [N + 1, 96] state array that is zeroed along the way (p0 = zeros), together with the sink row of q_state
+void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero = nullptr);
 // F coordinate frames of Nf atoms sharing one ids table [Nf,k] (F = 1: a plain collated batch); X strides in floats;
 // dmax_bits[F] must be zeroed. seg_of_atom / seg_end (F = 1 only, may be null): ragged structures that must behave like separate
 // calls - per-structure wrap-around target and max(D); dmax_bits then holds one zeroed word per structure

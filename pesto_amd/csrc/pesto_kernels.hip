@@ -27,7 +27,7 @@ __device__ __forceinline__ float g32_linear(const float* __restrict__ W, const L
 // ------------------------------------------------------------------------------------------------ embedding
 // q[i+1][:] = em(q0[i][:]) ; 8 atoms per 256-thread block, 32 lanes per atom.  model/model.py:34
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW em, int N, int nq, int n0,
-                                               const float* __restrict__ q0, float* __restrict__ q_state) {
+                                               const float* __restrict__ q0, float* __restrict__ q_state, float* __restrict__ p_zero) {
     __shared__ float xs[8][512];
     __shared__ float hs[8][64];
     const int g = threadIdx.x >> 5, s = threadIdx.x & 31;
@@ -45,6 +45,19 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW
         v = g32_linear(W, em.l[2], hs[g] + 32, s);
     }
     if (i < N) q_state[(size_t)(i + 1) * S + s] = v;
+    // p_zero (optional): p0 = zeros (model/model.py:37) and the sink rows of q and p (model_operations.py:17) written here instead of
+    // by two fill launches in front of the forward
+    if (p_zero) {
+        if (i < N) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p_zero[(size_t)(i + 1) * 96 + 32 * c + s] = 0.0f;
+        }
+        if (blockIdx.x == 0 && g == 0) {
+            q_state[s] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p_zero[32 * c + s] = 0.0f;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ geometry
@@ -111,7 +124,9 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
     __syncthreads();
     if (threadIdx.x == 0) {
         const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (m > 0.0f) atomicMax(dmax_bits + f, __float_as_uint(m));
+        // the maximum only grows: a block whose value does not beat what is already published (L2-served read) skips the atomic
+        if (m > 0.0f && __float_as_uint(m) > __hip_atomic_load(dmax_bits + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(dmax_bits + f, __float_as_uint(m));
     }
 }
 
@@ -531,8 +546,8 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state) {
-    hipLaunchKernelGGL(k_embed, dim3((N + 7) / 8), dim3(256), 0, st, W, em, N, nq, n0, q0, q_state);
+void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero) {
+    hipLaunchKernelGGL(k_embed, dim3((N + 7) / 8), dim3(256), 0, st, W, em, N, nq, n0, q0, q_state, p_zero);
 }
 
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
