@@ -124,9 +124,7 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
     __syncthreads();
     if (threadIdx.x == 0) {
         const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        // the maximum only grows: a block whose value does not beat what is already published (L2-served read) skips the atomic
-        if (m > 0.0f && __float_as_uint(m) > __hip_atomic_load(dmax_bits + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(dmax_bits + f, __float_as_uint(m));
+        if (m > 0.0f) atomicMax(dmax_bits + f, __float_as_uint(m));
     }
 }
 
