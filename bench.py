@@ -102,38 +102,60 @@ def source_hash():
 
 
 def cpu_baseline(config, sd, n_atoms, budget_s, config_key):
-    """The C oracle (port of the reference CPU path, OpenMP over atoms) on this host's cores, bounded sample."""
+    """The C oracle (port of the reference CPU path, OpenMP over atoms) on this host's cores, bounded sample: once on ALL cores
+    (the headline `value`) and once on the thread count rho was measured at (8), so that the reference-equivalent time
+    rho x t_port multiplies a time taken at EQUAL threads (the two do not commute: the port scales sub-linearly)."""
     from oracle import oracle
     X, ids, q, roa, R = make_batch(n_atoms, 1, 1, config["em"]["N0"])
     m = oracle.OracleModel(config, sd)
     ids32 = ids.astype(np.int32)
-    t0 = time.perf_counter()
-    m.forward_segments(X, ids32, q, roa, R, stop_after=2)     # touch pages / spin up the OpenMP team
-    t_warm = time.perf_counter() - t0
-    times = []
-    t_start = time.perf_counter()
-    while not times or (time.perf_counter() - t_start + np.mean(times) < budget_s and len(times) < 5):
-        t0 = time.perf_counter()
-        m.forward_segments(X, ids32, q, roa, R)
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     omp = os.environ.get("OMP_NUM_THREADS")
-    out = {"value": 1.0 / t, "unit": "structures/s", "cores": int(omp) if omp else cores, "kind": "port",
-           "sample": f"{len(times)} x one N={n_atoms} structure, all {len(config['sum'])} layers, C oracle (OpenMP); "
-                     f"median {t:.2f} s/structure (2-layer warm-up {t_warm:.2f} s)"}
+    all_threads = int(omp) if omp else cores
+
+    def sample(threads, budget, max_n):
+        oracle.set_threads(threads)
+        t0 = time.perf_counter()
+        m.forward_segments(X, ids32, q, roa, R, stop_after=2)     # touch pages / spin up the OpenMP team
+        t_warm = time.perf_counter() - t0
+        times = []
+        t_start = time.perf_counter()
+        while not times or (time.perf_counter() - t_start + np.mean(times) < budget and len(times) < max_n):
+            t0 = time.perf_counter()
+            m.forward_segments(X, ids32, q, roa, R)
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times)), len(times), t_warm
+
+    # the port does not scale to every host's core count (shared / hyper-threaded vCPUs): the headline is its BEST team size
+    tried = {}
+    for thr_ in sorted({min(32, all_threads), min(64, all_threads), all_threads}):
+        tried[thr_] = sample(thr_, 0.4 * budget_s / 3, 3)
+    best = min(tried, key=lambda k_: tried[k_][0])
+    t, n, t_warm = tried[best]
+    out = {"value": 1.0 / t, "unit": "structures/s", "cores": best, "kind": "port",
+           "sample": f"{n} x one N={n_atoms} structure, all {len(config['sum'])} layers, C oracle (OpenMP, {best} threads = the best of "
+                     f"{sorted(tried)} on this host's {cores} cores); median {t:.2f} s/structure (2-layer warm-up {t_warm:.2f} s)",
+           "seconds_per_structure_by_threads": {str(k_): v_[0] for k_, v_ in sorted(tried.items())}}
     # SURVEY 8d step 2: reference-equivalent CPU time = rho x t_port, rho = t_reference / t_port measured on equal cores in the
-    # build container (profiles/cpu_rho.py -> profiles/r02_cpu_rho.json, copied to BASELINE.md)
+    # build container (profiles/cpu_rho.py -> profiles/r02_cpu_rho.json, copied to BASELINE.md) and applied to the port's time at
+    # THAT thread count on this host
     rpath = os.path.join(ROOT, "profiles", "r02_cpu_rho.json")
     if os.path.exists(rpath):
         r = json.load(open(rpath))
         hit = [v for k, v in r["configs"].items() if k.startswith(config_key)]
         if hit:
             rho = float(np.mean([v["rho"] for v in hit]))
-            out["reference_equivalent"] = {"rho": rho, "seconds_per_structure": rho * t, "structures_per_s": 1.0 / (rho * t),
-                                           "provenance": f"rho = reference PyTorch CPU time / C-oracle time on the same {r['threads']} threads of the "
-                                                         f"build container (torch {r['torch']}), profiles/r02_cpu_rho.json; the reference "
-                                                         "itself cannot run on the GPU box"}
+            thr = int(r["threads"])
+            t8, n8, _ = sample(min(thr, all_threads), 0.4 * budget_s, 3)
+            oracle.set_threads(all_threads)
+            out["port_at_rho_threads"] = {"threads": min(thr, all_threads), "seconds_per_structure": t8, "structures_per_s": 1.0 / t8,
+                                          "sample": f"{n8} x the same structure", "speedup_of_the_best_team_over_these": t8 / t}
+            out["reference_equivalent"] = {"rho": rho, "threads": min(thr, all_threads), "seconds_per_structure": rho * t8,
+                                           "structures_per_s": 1.0 / (rho * t8),
+                                           "provenance": f"rho = reference PyTorch CPU time / C-oracle time on the same {thr} threads of the "
+                                                         f"build container (torch {r['torch']}), profiles/r02_cpu_rho.json, times the port's "
+                                                         f"time at {min(thr, all_threads)} threads on THIS host; the reference itself cannot "
+                                                         "run on the GPU box"}
     return out
 
 
@@ -412,6 +434,43 @@ def main():
              "hbm_bytes_per_forward_measured": traffic_file.get("hbm_bytes_per_forward") if traffic_file else None,
              "kernels": kern}
 
+    # ---- side sample: >= 200 consecutive steps, one HIP event pair per step on the launch stream (no host sync in between)
+    long_sample = None
+    if not args.no_extras:
+        n_long = max(200, args.steps)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_long + 1)]
+        barrier()
+        evs[0].record()
+        for i in range(n_long):
+            step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        dt = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_long)])
+        long_sample = {"steps": n_long, "ms_per_step_median": float(np.median(dt)), "ms_per_step_p10": float(np.percentile(dt, 10)),
+                       "ms_per_step_p90": float(np.percentile(dt, 90)), "ms_per_step_mean": float(dt.mean()),
+                       "structures_per_s_from_median": args.batch / float(np.median(dt)) * 1e3,
+                       "how": "HIP events between consecutive steps on torch's current stream (the stream the kernels are launched on)"}
+
+    # ---- the reference's own call: Model.forward(X, ids_topk, q, M) with the DENSE residue mask on the device (model/model.py:32);
+    # the mask is reduced to segments by k_mask_to_segments inside the call (the headline step hands the segments over directly)
+    ref_sig = None
+    if not args.no_extras:
+        Md = torch.zeros((n_atoms_total, R), dtype=torch.float32, device=dev)
+        Md[torch.arange(n_atoms_total, device=dev), road.long()] = 1.0
+        n_sig = max(5, min(args.steps, 20))
+        for _ in range(2):
+            zs = model(Xd, idsd, qd, Md)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_sig):
+            zs = model(Xd, idsd, qd, Md)
+        torch.cuda.synchronize()
+        t_sig = (time.perf_counter() - t1) / n_sig
+        ref_sig = {"call": "Model.forward(X, ids_topk, q, M): dense fp32 mask M [N, R] resident in HBM, reduced on the GPU by k_mask_to_segments",
+                   "mask_bytes": int(n_atoms_total) * int(R) * 4, "steps": n_sig, "ms_per_step": t_sig * 1e3,
+                   "structures_per_s": args.batch / t_sig, "bitwise_equal_to_segment_call": bool(torch.equal(zs, z))}
+        del Md
+
     # ---- side measurement: batch-1 latency (ms per structure when structures arrive one at a time)
     lat_ms = None
     if not args.no_latency and args.batch > 1:
@@ -447,6 +506,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_structure": elapsed / n_struct * 1e3,
             "ms_per_structure_batch1": lat_ms,
+            "long_sample": long_sample,
+            "reference_signature": ref_sig,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,

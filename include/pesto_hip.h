@@ -174,12 +174,24 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
 int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, const int32_t* res_of_atom, float* p_out, float* bfactor_out,
                       int32_t ptr_kind, void* stream);
 
+/* replaces: the dense residue mask argument M of Model.forward (model/model.py:32; built by encode_structure, src/data_encoding.py:73,
+ * one 1 per row) for callers that hold M itself: M float32 [N,R] (0/1) -> res_of_atom_out int32 [N], the column of each row's single
+ * member. One pass over M on the GPU (k_mask_to_segments). A row with zero or several members gives res_of_atom_out[i] = -1, an empty
+ * residue column makes res_of_atom_out[0] = -1: the forward that consumes the array then fails its residue-column check
+ * (PESTO_ERR_INVALID where the call synchronises, NaN logits otherwise) - SURVEY 8b's argument contract. With device pointers the call
+ * is asynchronous on `stream`; with host pointers it returns PESTO_ERR_INVALID itself. */
+int pesto_mask_to_segments(pesto_model* m, int64_t N, int64_t R, const float* M, int32_t* res_of_atom_out, int32_t ptr_kind, void* stream);
+
 /* ---- test hooks ----
  * Debug twins of the shipped kernels, selected per handle (the parity tests run every stage through each of them):
  * layer_kernels 0 = shipped (hybrid first layer; arithmetic per the precision policy), 1 = reference-formulation fp32 VALU
  * kernel (LDS-tiled, no MFMA);
  * knn_brute_force != 0: pesto_knn_collate searches every structure by brute force instead of the cell grid. */
 int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_force);
+/* work decomposition of the shipped state-update kernel: 0 = chosen per launch (default), 1 = rendezvous mode (every wave of a workgroup
+ * processes centres, the finish / prepare phase runs behind workgroup rendezvous), 2 = node-wave mode (four waves of twelve only
+ * finish / prepare). Both run the same arithmetic in the same order: results must not depend on the choice (tests force each). */
+int pesto_debug_edge_mode(pesto_model* m, int32_t mode);
 
 /* ---- per-stage entry points (HOST pointers), used by tests/ to pin each stage against the oracle ----
  * replaces: em.forward (model/model.py:34) */

@@ -35,6 +35,8 @@ def _load():
         lib.oracle_create.argtypes = [P(PestoConfig), c_p, i64, P(c_p)]
         lib.oracle_destroy.argtypes = [c_p]
         lib.oracle_destroy.restype = None
+        lib.oracle_set_threads.argtypes = [ctypes.c_int]
+        lib.oracle_set_threads.restype = None
         lib.oracle_embed.argtypes = [c_p, i64, c_p, c_p]
         lib.oracle_unpack.argtypes = [i64, ctypes.c_int, c_p, c_p, c_p, c_p, c_p]
         lib.oracle_layer.argtypes = [c_p, ctypes.c_int, i64, ctypes.c_int, c_p, c_p, c_p, c_p, c_p]
@@ -54,6 +56,11 @@ def _i32(a):
 
 def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def set_threads(n):
+    """OpenMP team size of the following oracle calls (n < 1: all cores)."""
+    _load().oracle_set_threads(int(n))
 
 
 def blob_size(config):

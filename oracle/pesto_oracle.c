@@ -13,6 +13,7 @@
  * [N,n,193] tensors instead), parallelised over atoms with OpenMP.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -121,6 +122,8 @@ int oracle_create(const pesto_config* cfg, const float* weights, int64_t n_weigh
 }
 
 void oracle_destroy(struct oracle_model* m) { if (m) { free(m->blob); free(m); } }
+/* OpenMP team size of the following calls (bench.py times the port at the thread count its rho was measured at); n < 1: all cores */
+void oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : omp_get_num_procs()); }
 
 /* ------------------------------------------------------------------ small dense pieces */
 /* torch.nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1 */
@@ -265,7 +268,7 @@ int oracle_layer(const struct oracle_model* m, int layer, int64_t N1, int k, con
         float* Kq = (float*)malloc(sizeof(float) * 64 * NK);
         float* Kp = (float*)malloc(sizeof(float) * 64 * 3 * NK);
         float* V = (float*)malloc(sizeof(float) * 64 * 2 * S);
-#pragma omp for schedule(dynamic, 16)
+#pragma omp for schedule(static, 2)   /* equal-cost atoms: no shared work counter (dynamic chunks of 16 left 68 of 256 threads idle) */
         for (int64_t i = 0; i < N1; ++i) {
             const float* qi = q_old + i * S;
             const float* pi = p_old + i * 3 * S;

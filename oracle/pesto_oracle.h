@@ -10,6 +10,7 @@ struct oracle_model;
 int oracle_blob_size(const pesto_config* cfg, int64_t* n);
 int oracle_create(const pesto_config* cfg, const float* weights, int64_t n_weights, struct oracle_model** out);
 void oracle_destroy(struct oracle_model* m);
+void oracle_set_threads(int n);   /* OpenMP threads of the following calls; n < 1: all cores */
 int oracle_embed(const struct oracle_model* m, int64_t N, const float* q0, float* q_out);
 int oracle_unpack(int64_t N, int k, const float* X, const int32_t* ids, int32_t* ids_s, float* D, float* R);
 int oracle_layer(const struct oracle_model* m, int layer, int64_t N1, int k, const int32_t* ids_s, const float* D,

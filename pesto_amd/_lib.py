@@ -60,6 +60,7 @@ ABI_SYMBOLS = [
     "pesto_stage_embed", "pesto_stage_unpack", "pesto_stage_layer", "pesto_stage_pool", "pesto_knn_collate",
     "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch", "pesto_get_kernel_timing",
     "pesto_set_precision", "pesto_get_status", "pesto_debug_select", "pesto_forward_structures",
+    "pesto_mask_to_segments", "pesto_debug_edge_mode",
 ]
 
 _lib = None
@@ -101,6 +102,8 @@ def load():
     lib.pesto_set_precision.argtypes = [c_p, i32]
     lib.pesto_get_status.argtypes = [c_p, P(i32), P(i64), P(i64)]
     lib.pesto_debug_select.argtypes = [c_p, i32, i32]
+    lib.pesto_debug_edge_mode.argtypes = [c_p, i32]
+    lib.pesto_mask_to_segments.argtypes = [c_p, i64, i64, c_p, c_p, i32, c_p]
     lib.pesto_postprocess.argtypes = [c_p, i64, i64, c_p, c_p, c_p, c_p, i32, c_p]
     lib.pesto_workspace_bytes.argtypes = [c_p, i64, i64, P(i64)]
     lib.pesto_synchronize.argtypes = [c_p]

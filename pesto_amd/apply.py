@@ -40,8 +40,8 @@ def save_results(results, path):
 def load_results(path):
     """{key: p [R, n_out]} from a file written by save_results."""
     d = np.load(path)
-    offs = d["offsets"]
-    return {str(k): d["p"][offs[i]:offs[i + 1]] for i, k in enumerate(d["keys"])}
+    offs, p, keys = d["offsets"], d["p"], d["keys"]      # NpzFile decompresses an array on EVERY access: materialise each once
+    return {str(k): p[offs[i]:offs[i + 1]] for i, k in enumerate(keys)}
 
 
 def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=24576, workers=8, on_error=print, results_path=None):

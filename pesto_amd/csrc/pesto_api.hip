@@ -64,6 +64,7 @@ struct pesto_model {
     int impl = 2;                          // 2 = MFMA layer (default), 1 = LDS-tiled VALU layer (pesto_debug_select: debug twin)
     int edge_blocks = 512;                 // persistent workgroups of the edge kernel (2 per CU)
     bool knn_brute = false;                // pesto_debug_select: brute-force k-NN for every structure
+    int edge_mode = 0;                     // pesto_debug_edge_mode: 0 = per launch, 1 = rendezvous, 2 = node waves
     int64_t n_forward = 0, n_rerun = 0;    // launch sequences run / repeated on the exact fp32 kernels after a range overflow
     // every launch sequence uses the ONE workspace below: sequences on different streams are ordered through this event
     hipEvent_t ws_ev = nullptr;
@@ -72,6 +73,7 @@ struct pesto_model {
     int* h_flags = nullptr;                // pinned host copy of the flags word (read back without a pageable staging copy)
     DevBuf col_seg, col_segend;            // pesto_forward_batch: structure of every atom, end offset of every structure
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
+    DevBuf in_M, mask_seen;               // pesto_mask_to_segments: host mask staging, one word per residue column
     DevBuf knn_off;                       // structure offsets of the last pesto_knn_collate call
     DevBuf knn_grids, knn_cnt, knn_cur, knn_cell, knn_sorted;   // cell grid of the large structures (pesto_knn_collate)
     DevBuf col_meta, col_ids, col_roa;    // pesto_forward_batch: per-structure table, collated ids / residue columns
@@ -153,7 +155,7 @@ int check_device_flag(pesto_model* m, hipStream_t st, int* flag_out = nullptr, i
     const int flag = *m->h_flags;
     if (flag_out) *flag_out = flag;
     if (flag & 1) return fail(PESTO_ERR_INVALID, "ids_topk contains an index outside [0, N]");
-    if (flag & 2) return fail(PESTO_ERR_INVALID, "res_of_atom contains an index outside [0, R)");
+    if (flag & 2) return fail(PESTO_ERR_INVALID, "res_of_atom contains an index outside [0, R) (from pesto_mask_to_segments: a row of M with != 1 member or an empty residue column)");
     if ((flag & 4) && !(ignore & 4))
         return fail(PESTO_ERR_RANGE, "an activation left the f16 range of the split-MFMA path (z is NaN): use PESTO_PRECISION_AUTO or "
                                      "PESTO_PRECISION_FP32");
@@ -229,7 +231,8 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
         for (int l = 0; l < L; ++l) {
             HIP_TRY(mark(nn_class(m->cfg.nn[l])));
             launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), rnb[cur], rcen, p[cur], nullptr, m->edge_blocks,
-                        edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1], l + 1 < L ? &m->img.layers[l + 1] : nullptr, rnb[cur ^ 1], rcen);
+                        edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1], l + 1 < L ? &m->img.layers[l + 1] : nullptr, rnb[cur ^ 1], rcen,
+                        m->edge_mode);
             cur ^= 1;
         }
         HIP_TRY(mark(-1));
@@ -348,7 +351,7 @@ int pesto_destroy(pesto_model* m) {
     for (auto& e : m->kev) if (e) (void)hipEventDestroy(e);
     if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
-                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->rec_nb2, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa, &m->knn_grids, &m->knn_cnt, &m->knn_cur, &m->knn_cell, &m->knn_sorted, &m->col_seg, &m->col_segend})
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->rec_nb2, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa, &m->knn_grids, &m->knn_cnt, &m->knn_cur, &m->knn_cell, &m->knn_sorted, &m->col_seg, &m->col_segend, &m->in_M, &m->mask_seen})
         b->release();
     delete m;
     return 0;
@@ -389,6 +392,13 @@ int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_
     if (layer_kernels != 0 && layer_kernels != 1) return fail(PESTO_ERR_INVALID, "layer_kernels must be 0 or 1");
     m->impl = layer_kernels == 1 ? 1 : 2;
     m->knn_brute = knn_brute_force != 0;
+    return 0;
+}
+
+int pesto_debug_edge_mode(pesto_model* m, int32_t mode) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (mode < 0 || mode > 2) return fail(PESTO_ERR_INVALID, "mode must be 0 (per launch), 1 (rendezvous) or 2 (node waves)");
+    m->edge_mode = mode;
     return 0;
 }
 
@@ -662,6 +672,34 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
     return 0;
 }
 
+int pesto_mask_to_segments(pesto_model* m, int64_t N, int64_t R, const float* M, int32_t* res_of_atom_out, int32_t ptr_kind, void* stream) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || R > N || !M || !res_of_atom_out) return fail(PESTO_ERR_INVALID, "bad arguments");
+    if (ptr_kind != PESTO_PTR_HOST && ptr_kind != PESTO_PTR_DEVICE) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
+    HIP_TRY(hipSetDevice(m->device));
+    if (m->mask_seen.ensure((size_t)R * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    if (ptr_kind == PESTO_PTR_DEVICE) {
+        Sequence seq(m, (hipStream_t)stream);
+        if (seq.rc) return seq.rc;
+        launch_mask_to_segments((hipStream_t)stream, (int)N, (int)R, M, res_of_atom_out, m->mask_seen.as<int>());
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    if (m->in_M.ensure((size_t)N * R * 4) || m->in_roa.ensure((size_t)N * 4)) return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    Sequence seq(m, st);
+    if (seq.rc) return seq.rc;
+    HIP_TRY(hipMemcpyAsync(m->in_M.p, M, (size_t)N * R * 4, hipMemcpyHostToDevice, st));
+    launch_mask_to_segments(st, (int)N, (int)R, m->in_M.as<float>(), m->in_roa.as<int>(), m->mask_seen.as<int>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(res_of_atom_out, m->in_roa.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < N; ++i)
+        if (res_of_atom_out[i] < 0)
+            return fail(PESTO_ERR_INVALID, i == 0 ? "M: atom 0 has != 1 residue, or a residue column is empty" : "M: atom %lld belongs to != 1 residue", (long long)i);
+    return 0;
+}
+
 int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, const int32_t* res_of_atom, float* p_out, float* bfactor_out,
                       int32_t ptr_kind, void* stream) {
     if (check_model(m)) return PESTO_ERR_INVALID;
@@ -774,7 +812,7 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
         launch_node(st, m->W, nullptr, L, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), ev, err_ptr(m));
         if (ev == 0) {      // shipped path: the finish phase runs inside the edge kernel, new state in the other buffer pair
             launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), nullptr, m->edge_blocks, ev, err_ptr(m),
-                        m->q_a.as<float>(), m->q_b.as<float>(), m->p_b.as<float>());
+                        m->q_a.as<float>(), m->q_b.as<float>(), m->p_b.as<float>(), nullptr, nullptr, nullptr, m->edge_mode);
         } else {
             launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->edge_blocks, ev, err_ptr(m));
             launch_node(st, m->W, L, nullptr, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), ev, err_ptr(m));

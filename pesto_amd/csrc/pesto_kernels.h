@@ -25,7 +25,8 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags,
                  const float* q_state = nullptr, float* q_out = nullptr, float* p_out = nullptr, const LayerW* next = nullptr,
-                 float* rec_nb_out = nullptr, float* rec_cen_out = nullptr);
+                 float* rec_nb_out = nullptr, float* rec_cen_out = nullptr, int mode = 0);
+// mode (shipped path only): 0 = work decomposition chosen per launch, 1 = rendezvous mode, 2 = node-wave mode (pesto_debug_edge_mode)
 // q_out / p_out non-null (variant 0 only): the edge kernel also applies the layer's output MLPs (finish phase) and writes the new
 // state there - p_state / q_state (the old state, still gathered by other workgroups) must be different buffers; Z is not used.
 // next non-null: it also writes layer `next`'s records of the new state into rec_nb_out / rec_cen_out (prepare phase; buffers
@@ -44,6 +45,9 @@ int knn_cells_per_struct();
 void launch_collate(hipStream_t st, int n_total, int n_struct, const void* meta, const void* ids_raw, int ids_kind, const int* roa_raw,
                     int* ids_out, int* roa_out, int* seg_of_atom, int* seg_end, int* err_flag);
 void launch_segments(hipStream_t st, int n_total, int n_struct, const int* seg_end, int* seg_of_atom);
+// dense mask M [N,R] -> roa [N] (column of the single member per row, -1 for rows with != 1 member; roa[0] = -1 if a column is empty);
+// seen: R ints of scratch
+void launch_mask_to_segments(hipStream_t st, int N, int R, const float* M, int* roa, int* seen);
 void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z, const int* roa, float* p_out, float* bf_out, int* err_flag);
 void debug_print_phase_cycles();   // no-op unless built with -DPESTO_PROFILE_PHASES
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,

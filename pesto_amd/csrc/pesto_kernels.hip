@@ -870,6 +870,53 @@ __global__ __launch_bounds__(256) void k_postprocess(int N, int R, int n_out, co
     }
 }
 
+// Dense residue mask -> segments (Model.forward's M argument, model/model.py:32; one 1 per row by construction, src/data_encoding.py:73).
+// One wave per row: the lanes sweep the R columns (16-byte loads when the row is 16-byte aligned), count the members (> 0.5, as the
+// host check does) and keep the column of the last one; a row with exactly one member gets its column, any other row -1. Every valid
+// row marks its column in `seen`; k_mask_check poisons roa[0] when a column stayed empty. No host round trip: a poisoned entry fails
+// the residue-column check of the forward that consumes the array.
+__global__ __launch_bounds__(256) void k_mask_to_segments(int N, int R, const float* __restrict__ M, int* __restrict__ roa, int* __restrict__ seen) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float* row = M + (size_t)i * R;
+    int cnt = 0, col = -1;
+    int c0 = 0;
+    if ((((size_t)row) & 15) == 0) {
+        const int R4 = R >> 2;
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        for (int c = lane; c < R4; c += 64) {
+            const float4 v = row4[c];
+            if (v.x > 0.5f) { ++cnt; col = 4 * c; }
+            if (v.y > 0.5f) { ++cnt; col = 4 * c + 1; }
+            if (v.z > 0.5f) { ++cnt; col = 4 * c + 2; }
+            if (v.w > 0.5f) { ++cnt; col = 4 * c + 3; }
+        }
+        c0 = R4 << 2;
+    }
+    for (int c = c0 + lane; c < R; c += 64)
+        if (row[c] > 0.5f) { ++cnt; col = c; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o);
+        col = max(col, __shfl_xor(col, o));
+    }
+    if (lane == 0) {
+        const bool ok = cnt == 1;
+        roa[i] = ok ? col : -1;
+        if (ok) seen[col] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_mask_check(int R, const int* __restrict__ seen, int* __restrict__ roa) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < R && seen[r] == 0) roa[0] = -1;      // (benign race: every writer stores the same value)
+}
+void launch_mask_to_segments(hipStream_t st, int N, int R, const float* M, int* roa, int* seen) {
+    (void)hipMemsetAsync(seen, 0, (size_t)R * sizeof(int), st);
+    hipLaunchKernelGGL(k_mask_to_segments, dim3((N + 3) / 4), dim3(256), 0, st, N, R, M, roa, seen);
+    hipLaunchKernelGGL(k_mask_check, dim3((R + 255) / 256), dim3(256), 0, st, R, seen, roa);
+}
+
 void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z, const int* roa, float* p_out, float* bf_out, int* err_flag) {
     const int64_t n = (int64_t)R * n_out + (bf_out ? (int64_t)N * n_out : 0);
     hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, N, R, n_out, z, roa, p_out, bf_out, err_flag);

@@ -57,8 +57,12 @@ __device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
         const f32x2 x = {v[j], v[j + 1]};
         const f16x2 h = __builtin_convertvector(x, f16x2);
         hi[j] = h[0]; hi[j + 1] = h[1];
+#ifdef PESTO_ABL_NOSPLIT   // ablation: no residual (results wrong): -8 VALU per eight values
+        lo[j] = h[0]; lo[j + 1] = h[1];
+#else
         lo[j] = (_Float16)__builtin_fmaf((float)h[0], m1, v[j]);
         lo[j + 1] = (_Float16)__builtin_fmaf((float)h[1], m1, v[j + 1]);
+#endif
     }
 }
 // Range guard of the f16-split path. A value beyond +-65504 splits into hi = +-inf, lo = -+inf, and every MFMA output fed by
@@ -108,6 +112,9 @@ __device__ __forceinline__ f32x4 elu4(f32x4 v) {
 // log2-domain ELU of the f16-split edge MLPs (pesto_schema.cpp): t = log2(e) x in, log2(e) ELU(x) out - the exp is a bare v_exp_f32
 // and scale + "-1" collapse into one packed fma: 2.5 VALU + 1 transcendental per value instead of 3 + 1
 __device__ __forceinline__ f32x4 elu4s(f32x4 t) {
+#ifdef PESTO_ABL_NOELU   // ablation: one v_max per value instead of exp + fma + med3 (keeps the magnitudes of the activations)
+    return f32x4{fmaxf(t[0], -1.4426950f), fmaxf(t[1], -1.4426950f), fmaxf(t[2], -1.4426950f), fmaxf(t[3], -1.4426950f)};
+#endif
     constexpr float C = 1.44269504088896340736f;
     f32x4 ex = f32x4{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
     ex = ex * C - C;
@@ -647,6 +654,9 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
 // not bytes or VALU, bounded this kernel. The MFMA operand layout wants lane = 16 * chunk + edge; values move there with
 // ds_bpermute (LDS crossbar, no LDS storage): MFMA lane (e, g) pulls from producer lane 4e + g.
 __device__ __forceinline__ float bperm(int src_byte, float v) {
+#ifdef PESTO_ABL_NOBPERM   // ablation: the A_j chunks stay in the producer lanes (results wrong): -16 ds_bpermute per tile and pass
+    return v;
+#endif
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_byte, __builtin_bit_cast(int, v)));
 }
 __device__ __forceinline__ f32x4 to_mfma_lanes(f32x4 v, int lane) {
@@ -1867,9 +1877,9 @@ static bool node_wave_mode(int nn, int n_work) {
     const double cost = nn == 8 ? 0.90 : nn == 16 ? 0.965 : nn == 32 ? 1.0 : 1.023;
     return rounds_paid(n_work, 8, subs) * cost < rounds_paid(n_work, 12, subs);
 }
-static void launch_edge_full(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks) {
+static void launch_edge_full(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks, int mode) {
     const int a = lw.nn == 64 ? 1 : 2;                                     // centres per 64-row item (nn = 8: one-tile items of two centres)
-    const bool nw = node_wave_mode(lw.nn, (N1 + a - 1) / a);
+    const bool nw = mode == 0 ? node_wave_mode(lw.nn, (N1 + a - 1) / a) : mode == 2;
     switch (lw.nn) {
         case 8: if (nw) launch_edge_k<8, 12, false, true, true, 1, true, 8>(st, W, lw, N1, io, max_blocks);
                 else launch_edge_k<8, 12, false, true, true, 1, true>(st, W, lw, N1, io, max_blocks);
@@ -1891,7 +1901,7 @@ static void launch_edge_full(hipStream_t st, const float* W, const LayerW& lw, i
 // variant 1: everything on exact fp32 MFMA (4 waves per workgroup, explicit cross-tile prefetch), full 2 KB neighbour records
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags,
-                 const float* q_state, float* q_out, float* p_out, const LayerW* next, float* rec_nb_out, float* rec_cen_out) {
+                 const float* q_state, float* q_out, float* p_out, const LayerW* next, float* rec_nb_out, float* rec_cen_out, int mode) {
     PrepW pw{};
     if (next) pw = PrepW{next->h_ua, next->h_gc, next->h_n0, next->n_b1s, next->n_bn0, next->n_bn1, next->n_bn2};
     const EdgeIO io{ids_s, geo, rec_nb, rec_cen, p_state, Z, flags, q_state, q_out, p_out, pw, next ? rec_nb_out : nullptr, next ? rec_cen_out : nullptr};
@@ -1905,7 +1915,7 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
         // fine work items (one centre each for nn >= 16): when they outnumber the 2,048 wave slots of eight-wave workgroups, twelve
         // waves give (almost) every item its own wave instead of handing half of the waves two
         const int n_fine = lw.nn == 8 ? (N1 + 1) / 2 : N1;
-        if (n_work >= 2048) launch_edge_full(st, W, lw, N1, io, 256);
+        if (n_work >= 2048 || mode != 0) launch_edge_full(st, W, lw, N1, io, 256, mode);
         else if (n_fine > 2048) launch_edge_fin<12, true>(st, W, lw, N1, io, 256);
         else launch_edge_fin<8, true>(st, W, lw, N1, io, 256);     // 63 KB of constants: one workgroup per CU; fine work items
     }

@@ -36,6 +36,7 @@ class Model:
         self.precision = str(precision).lower()
         self._cc = _lib.make_c_config(self.config, self.precision)
         self._debug = (0, 0)        # pesto_debug_select(layer_kernels, knn_brute_force): test hook
+        self._edge_mode = 0         # pesto_debug_edge_mode: test hook
         self._blob = None
         self._handle = None
         self._gpu = 0
@@ -75,6 +76,14 @@ class Model:
         self._debug = (int(layer_kernels), int(bool(knn_brute_force)))
         if self._handle is not None:
             _lib.check(_lib.load().pesto_debug_select(self._handle, *self._debug))
+        return self
+
+    def debug_edge_mode(self, mode=0):
+        """Test hook (pesto_debug_edge_mode): 0 = work decomposition of the state-update kernel chosen per launch, 1 = rendezvous
+        mode, 2 = node-wave mode. Results must not depend on it."""
+        self._edge_mode = int(mode)
+        if self._handle is not None:
+            _lib.check(_lib.load().pesto_debug_edge_mode(self._handle, self._edge_mode))
         return self
 
     def state_dict(self):
@@ -142,6 +151,8 @@ class Model:
             self._handle = h
             if self._debug != (0, 0):
                 _lib.check(lib.pesto_debug_select(h, *self._debug))
+            if self._edge_mode:
+                _lib.check(lib.pesto_debug_edge_mode(h, self._edge_mode))
         return self._handle
 
     @property
@@ -149,17 +160,30 @@ class Model:
         return self._ensure()
 
     # ------------------------------------------------------------------ forward
+    def _segments(self, M):
+        """(res_of_atom, R) of the dense residue mask M [N,R]. A mask on the GPU is reduced there by k_mask_to_segments
+        (pesto_mask_to_segments: one pass over M on torch's current stream, no host round trip, no ATen kernel); rows with != 1 member
+        or an empty residue column poison the array, so the forward that consumes it reports PESTO_ERR_INVALID / NaN logits."""
+        if _is_torch(M) and M.is_cuda:
+            import torch
+            if M.device.index != self._gpu:
+                raise RuntimeError(f"inputs are on cuda:{M.device.index} but the model is on cuda:{self._gpu} (use .to())")
+            Mc = M.detach()
+            if Mc.dtype != torch.float32 or not Mc.is_contiguous():
+                Mc = Mc.to(torch.float32).contiguous()
+            N, R = int(Mc.shape[0]), int(Mc.shape[1])
+            roa = torch.empty((N,), dtype=torch.int32, device=M.device)
+            stream = torch.cuda.current_stream(M.device).cuda_stream
+            _lib.check(_lib.load().pesto_mask_to_segments(self._ensure(), N, R, Mc.data_ptr(), roa.data_ptr(), _lib.PTR_DEVICE, stream))
+            return roa, R
+        if self.validate:
+            return mask_to_segments(M)
+        Mn = M.detach().numpy() if _is_torch(M) else np.asarray(M)
+        return Mn.argmax(1).astype(np.int32), int(Mn.shape[1])
+
     def forward(self, X, ids_topk, q0, M):
         """z = forward(X [N,3] f32, ids_topk [N,k] int (1-based, 0 = sink), q0 [N,N0] f32, M [N,R] 0/1) -> [R,N2] f32"""
-        if self.validate:
-            roa, R = mask_to_segments(M)
-        elif _is_torch(M):
-            import torch
-            R = int(M.shape[1])
-            roa = M.argmax(dim=1).to(torch.int32)
-        else:
-            R = int(M.shape[1])
-            roa = np.asarray(M).argmax(1).astype(np.int32)
+        roa, R = self._segments(M)
         return self.forward_segments(X, ids_topk, q0, roa, R)
 
     __call__ = forward
@@ -281,15 +305,7 @@ class Model:
         ``for i in frames: z_i = model(X_traj[:, i], ids_topk, q, M)`` (md_analysis/apply_model_md.ipynb cell 6) computes, with
         several frames per kernel launch. ``X_frames``: [F, N, 3] (frame_axis=0) or the reference's [N, F, 3] trajectory
         tensor (frame_axis=1); strided views are read in place (no copy). Other arguments as forward()."""
-        if self.validate:
-            roa, R = mask_to_segments(M)
-        elif _is_torch(M):
-            import torch
-            R = int(M.shape[1])
-            roa = M.argmax(dim=1).to(torch.int32)
-        else:
-            R = int(M.shape[1])
-            roa = np.asarray(M).argmax(1).astype(np.int32)
+        roa, R = self._segments(M)
         return self.forward_frames_segments(X_frames, ids_topk, q0, roa, R, frame_axis, frames_per_launch)
 
     def forward_frames_segments(self, X_frames, ids_topk, q0, res_of_atom, R, frame_axis=0, frames_per_launch=0):

@@ -61,25 +61,36 @@ def batches(indices, sizes, max_atoms, pack=True):
     return sorted((sorted(b) for b in bins), key=lambda b: b[0])
 
 
-def _skippable():
+# pesto_status codes that describe ONE structure's inputs (include/pesto_hip.h): PESTO_ERR_INVALID, PESTO_ERR_RANGE
+_PER_STRUCTURE_CODES = (-1, -5)
+
+
+def _is_skippable(exc):
     """Per-structure failures the bulk loop skips (the reference driver wraps each structure in try/except and continues,
-    interfaceome/apply_model.py:57-82): bad inputs reported by the library or the host checks. Anything else - a missing
-    library, a HIP failure, out of memory - is systemic and propagates."""
+    interfaceome/apply_model.py:57-82): bad inputs reported by the host checks (ValueError) or by the library with a per-structure
+    status (PESTO_ERR_INVALID, PESTO_ERR_RANGE). Anything else - a missing library (no code), PESTO_ERR_HIP, PESTO_ERR_NOMEM - is
+    systemic: retrying the remaining structures would silently truncate the results, so it propagates."""
     from ._lib import PestoError
-    return (PestoError, ValueError)
+    if isinstance(exc, PestoError):
+        return exc.code in _PER_STRUCTURE_CODES
+    return isinstance(exc, ValueError)
 
 
-def forward_local(forward_fn, structures, indices, max_atoms=24576):
+class AllStructuresFailed(RuntimeError):
+    """Every structure of a rank failed its per-structure checks: a systemic problem, not a bad input."""
+
+
+def forward_local(forward_fn, structures, indices, max_atoms=24576, raise_if_all_failed=True):
     """Run ``forward_fn(X, ids_topk, q, M) -> z`` (or a pesto_amd.Model) over this rank's structures, collating several per launch.
     ``structures[i] = (X, ids_topk0, q, M)`` with the per-structure contract of pesto_amd.topology.
     Returns {index: z_i (numpy [R_i, n_out])}.  With a Model the launches use PESTO_BATCH_INDEPENDENT: every structure gets
     the result of its own call whatever it was grouped with, so any partition over ranks gives the same bits.
-    A structure whose batch raises PestoError / ValueError is retried alone, logged and skipped (None) on a second failure;
-    if EVERY structure of this rank fails the last error is re-raised (a systemic problem, not a bad input)."""
+    A structure whose batch raises a per-structure error (_is_skippable) is retried alone, logged and skipped (None) on a second
+    failure; any other error propagates at once. If EVERY structure of this rank fails the last error is re-raised
+    (raise_if_all_failed; forward_sharded defers that until after its collective so that no rank is left waiting in it)."""
     from .topology import collate_batch_features
     sizes = [np.asarray(s[0]).shape[0] for s in structures]
     results = {}
-    skippable = _skippable()
 
     def run(group):
         if hasattr(forward_fn, "forward_batch"):      # a pesto_amd.Model: collate on the device (pesto_forward_batch)
@@ -99,7 +110,9 @@ def forward_local(forward_fn, structures, indices, max_atoms=24576):
     for group in batches(indices, sizes, max_atoms):
         try:
             run(group)
-        except skippable as e_group:
+        except Exception as e_group:
+            if not _is_skippable(e_group):
+                raise
             if len(group) == 1:
                 log.warning("structure %d skipped: %s", group[0], e_group)
                 results[group[0]] = None
@@ -108,11 +121,13 @@ def forward_local(forward_fn, structures, indices, max_atoms=24576):
             for i in group:
                 try:
                     run([i])
-                except skippable as e:
+                except Exception as e:
+                    if not _is_skippable(e):
+                        raise
                     log.warning("structure %d skipped: %s", i, e)
                     results[i] = None
                     last_error = e
-    if indices and last_error is not None and all(results.get(i) is None for i in indices):
+    if raise_if_all_failed and indices and last_error is not None and all(results.get(i) is None for i in indices):
         raise last_error
     return results
 
@@ -126,10 +141,11 @@ def _collective_device(group=None):
     return torch.device("cpu")
 
 
-def gather_results(local, n_total, n_out, group=None, device=None):
+def gather_results(local, n_total, n_out, group=None, device=None, failed_ranks=None):
     """All ranks receive every structure's z. ``local``: {index: array or None}. Three small collectives:
     all_gather of (index, rows) descriptors and row counts, all_gather of row payloads padded to the largest rank.
-    ``device``: where the collective tensors live; default from the group's backend (cuda for nccl = RCCL, cpu for gloo)."""
+    ``device``: where the collective tensors live; default from the group's backend (cuda for nccl = RCCL, cpu for gloo).
+    ``failed_ranks`` (optional list): receives the ranks that owned structures and delivered none (same answer on every rank)."""
     import torch
     import torch.distributed as dist
     if device is None:
@@ -160,12 +176,17 @@ def gather_results(local, n_total, n_out, group=None, device=None):
         d = all_desc[r].cpu().numpy()
         pay = all_pay[r].cpu().numpy()
         off = 0
+        owned = good = 0
         for i, nrow in d:
             if i < 0:
                 break
+            owned += 1
             if nrow >= 0:
                 out[int(i)] = pay[off:off + nrow].copy()
                 off += int(nrow)
+                good += 1
+        if failed_ranks is not None and owned > 0 and good == 0:
+            failed_ranks.append(r)
     return out
 
 
@@ -179,5 +200,11 @@ def forward_sharded(forward_fn, structures, n_out, max_atoms=24576, group=None, 
         return [local[i] for i in range(len(structures))]
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     mine = partition(sizes, world)[rank]
-    local = forward_local(forward_fn, structures, mine, max_atoms)
-    return gather_results(local, len(structures), n_out, group=group, device=device)
+    # a rank whose structures ALL fail must still enter the collective (the others are already waiting in it): the verdict is taken
+    # from the gathered descriptors, identically on every rank
+    local = forward_local(forward_fn, structures, mine, max_atoms, raise_if_all_failed=False)
+    failed = []
+    out = gather_results(local, len(structures), n_out, group=group, device=device, failed_ranks=failed)
+    if failed:
+        raise AllStructuresFailed(f"every structure of rank(s) {failed} failed (see that rank's log): a systemic problem, not a bad input")
+    return out

@@ -43,7 +43,7 @@ def weights(tag):
         from pesto_amd.weights import stack_layers
         if tag == "i_v4_1":
             _weights_cache[tag] = stack_layers(weights("i_v4_0"), CONFIGS["i_v4_1"], 0.5)
-        elif tag == "i_v3_1_trained":  # the reference's trained i_v3_1 (model/save/i_v3_1_2021-05-28_12-40/model.pt) as arrays
+        elif tag == "i_v3_1_trained":  # the reference's trained i_v3_1 (model/save/i_v3_1_2021-05-28_12-40/model_ckpt.pt) as arrays
             d = golden("weights_i_v3_1")
             _weights_cache[tag] = {k: d[k] for k in d.files}
         elif tag == "i_v3_1":  # hybrid: own em/dm + i_v3_0 sum/spl (see tests/golden/make_golden.py)

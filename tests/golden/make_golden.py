@@ -323,7 +323,7 @@ PDBS_TEST_GOLDEN = ("V9_2V9T_1_B:0", "JT_1JTD_1_B:0", "WU_2WUS_1_A:0", "SJ_3SJA_
 def main_r2():
     """Round-2 goldens: (1) BASELINE config 4 - chains of pdbs_test/ through the i_v4_1 architecture (stacked weights), one
     structure per call like the reference's bulk loop (interfaceome/apply_model.py:57-82, apply_model.ipynb:139-167);
-    (2) the TRAINED i_v3_1 (model/save/i_v3_1_2021-05-28_12-40/model.py:10-22 + model.pt) on 2CUA, fp32 and fp64 - its
+    (2) the TRAINED i_v3_1 (model/save/i_v3_1_2021-05-28_12-40/model.py:10-22 + model_ckpt.pt) on 2CUA, fp32 and fp64 - its
     states reach 4e5, beyond the f16 range of the split-MFMA path; (3) BASELINE config 3 at its stated size (i_v3_0, N=3000)."""
     import glob
     # (1) config 4

@@ -738,3 +738,118 @@ def test_calls_on_different_streams_share_the_workspace_safely():
         torch.cuda.synchronize()
         assert np.abs(z_side.cpu().numpy() - g["z"]).max() < 1e-4 and torch.equal(z_side, z_side2)
         assert np.abs(z_host - g2["z"]).max() < 1e-4 and np.array_equal(z_def.cpu().numpy(), z_host)
+
+
+# ---------------------------------------------------------------------------------------------- both work decompositions of the layer kernel
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("layer", [0, 4, 8, 12])
+def test_stage_layer_forced_edge_mode(layer, mode):
+    """One layer of every nn (8, 16, 32, 64) through the rendezvous mode (1) and the node-wave mode (2) of the shipped kernel
+    (pesto_debug_edge_mode; by default a cost model picks per launch) against the reference's per-layer goldens."""
+    g = golden("ops_i_v4_0_crop200")
+    m = _model("i_v4_0", "mfma").debug_edge_mode(mode)
+    m.stage_unpack(g["X"], g["ids_topk"].astype(np.int32))
+    q, p = m.stage_layer(layer, g[f"L{layer}_q_in"], g[f"L{layer}_p_in"])
+    assert np.abs(q - g[f"L{layer}_q_out"]).max() < stage_tol(g[f"L{layer}_q_out"])
+    assert np.abs(p - g[f"L{layer}_p_out"]).max() < stage_tol(g[f"L{layer}_p_out"])
+    assert np.all(q[0] == 0) and np.all(p[0] == 0)
+
+
+@pytest.mark.parametrize("fixture", ["fwd_i_v4_0_2AYO", "edge_n40", "edge_coincident"])
+def test_forward_golden_forced_edge_modes_agree_bitwise(fixture):
+    """Whole forward in each forced mode against the reference golden; the modes run the same arithmetic in the same order, so they
+    must agree bit for bit with each other and with the per-launch choice."""
+    g = golden(fixture)
+    roa = g["res_of_atom"]
+    zs = []
+    for mode in (0, 1, 2):
+        m = _model("i_v4_0", "mfma").debug_edge_mode(mode)
+        z = m.forward_segments(g["X"], g["ids_topk"].astype(np.int64), onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
+        assert np.abs(z - g["z"]).max() < 1e-4
+        zs.append(z)
+    assert np.array_equal(zs[0], zs[1]) and np.array_equal(zs[0], zs[2])
+
+
+@pytest.mark.parametrize("atoms,batch", [(1025, 9), (6145, 2)])
+def test_odd_launch_shapes_both_modes_vs_oracle(atoms, batch):
+    """Launch shapes that leave partly filled rounds (9 x 1,025 atoms: one over a round multiple per structure; 2 x 6,145: one atom
+    over the 6,144-atom round of the twelve-wave kernels) through both modes: against the CPU ORACLE on the same inputs, each mode
+    deterministic, modes bit-identical, and batch == one call per structure bit for bit."""
+    from pesto_amd.topology import mask_to_segments, synthetic_structure
+    structs = [synthetic_structure(atoms, 11 * b + atoms, n0=30) for b in range(batch)]
+    o = _oracle("i_v4_0")
+    ref = []
+    for X, ids0, q, M in structs[:2]:
+        roa, R = mask_to_segments(M)
+        ref.append(o.forward_segments(X, (ids0 + 1).astype(np.int32), q, roa, R))
+    out = {}
+    for mode in (1, 2):
+        m = _model("i_v4_0", "mfma").debug_edge_mode(mode)
+        zb = m.forward_batch(structs, independent=True)
+        assert all(np.array_equal(a, b) for a, b in zip(zb, m.forward_batch(structs, independent=True)))
+        for i in range(2):
+            assert np.abs(zb[i] - ref[i]).max() < 1e-4
+        for i in (0, batch - 1):
+            assert np.array_equal(zb[i], m.forward_batch([structs[i]], independent=True)[0])
+        out[mode] = zb
+    assert all(np.array_equal(a, b) for a, b in zip(out[1], out[2]))
+
+
+# ---------------------------------------------------------------------------------------------- dense mask -> segments on the GPU
+def test_mask_to_segments_kernel_and_the_reference_signature():
+    """Model.forward(X, ids_topk, q, M) with the dense mask ON THE DEVICE (model/model.py:32): M is reduced to res_of_atom by
+    k_mask_to_segments (no ATen kernel on the path); odd R (row starts not 16-byte aligned) and aligned R; a row with two members,
+    an all-zero row and an empty residue column are rejected through the forward's residue-column check."""
+    import ctypes
+
+    import torch
+    from pesto_amd import _lib
+    from pesto_amd._lib import PestoError
+    dev = torch.device("cuda:0")
+    g = golden("fwd_i_v4_0_2CUA")
+    roa = g["res_of_atom"].astype(np.int64)
+    R = int(roa.max()) + 1
+    m = _model("i_v4_0", "mfma").to(dev)
+    for pad in (0, 1, 2, 3):                      # R + pad columns: the extra residues get one atom each of a trailing dummy block
+        Rp = R + pad
+        N = roa.size
+        M = np.zeros((N, Rp), np.float32)
+        M[np.arange(N), roa] = 1.0
+        if pad:
+            continue_rows = np.zeros((pad, Rp), np.float32)
+            continue_rows[np.arange(pad), R + np.arange(pad)] = 1.0
+            Mfull = np.concatenate([M, continue_rows])
+        else:
+            Mfull = M
+        Md = torch.from_numpy(Mfull).to(dev)
+        seg, Rk = m._segments(Md)
+        assert Rk == Rp and seg.dtype == torch.int32
+        assert np.array_equal(seg.cpu().numpy(), Mfull.argmax(1))
+    M = np.zeros((roa.size, R), np.float32)
+    M[np.arange(roa.size), roa] = 1.0
+    args = [torch.from_numpy(g["X"]).to(dev), torch.from_numpy(g["ids_topk"].astype(np.int64)).to(dev),
+            torch.from_numpy(onehot(g["q_idx"], 30)).to(dev)]
+    z = m(*args, torch.from_numpy(M).to(dev))
+    assert (z.cpu() - torch.from_numpy(g["z"])).abs().max() < 1e-4
+    for kind in ("two_members", "no_member", "empty_column"):
+        Mb = M.copy()
+        if kind == "two_members":
+            Mb[7, (roa[7] + 1) % R] = 1.0
+        elif kind == "no_member":
+            Mb[11] = 0.0
+        else:
+            r = int(roa[5])
+            rows = np.where(roa == r)[0]
+            Mb[rows] = 0.0
+            Mb[rows, (r + 1) % R] = 1.0
+        with pytest.raises(PestoError):
+            m(*args, torch.from_numpy(Mb).to(dev))
+            torch.cuda.synchronize()
+    # host-pointer form reports the bad row itself
+    lib = _lib.load()
+    Mb = M.copy(); Mb[11] = 0.0
+    out = np.empty(roa.size, np.int32)
+    rc = lib.pesto_mask_to_segments(m.handle, roa.size, R, Mb.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), _lib.PTR_HOST, None)
+    assert rc == -1 and b"atom 11" in lib.pesto_last_error()
+    rc = lib.pesto_mask_to_segments(m.handle, roa.size, R, M.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), _lib.PTR_HOST, None)
+    assert rc == 0 and np.array_equal(out, roa)

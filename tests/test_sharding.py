@@ -100,9 +100,27 @@ def test_failed_structure_is_skipped_not_fatal():
 
 
 def test_systemic_failure_propagates():
-    """Only per-structure input errors (PestoError / ValueError) are skipped; anything else, or a rank on which EVERY structure
+    """Only per-structure input errors (ValueError, PestoError with PESTO_ERR_INVALID / PESTO_ERR_RANGE) are skipped; anything else
+    - a PestoError carrying PESTO_ERR_HIP / PESTO_ERR_NOMEM or no code, any other exception - or a rank on which EVERY structure
     fails, is an error of the run, not of a structure."""
-    structures = _structures()[:2]
+    from pesto_amd._lib import PestoError
+    structures = _structures()[:3]
+
+    def make(code):
+        def fwd(X, ids, q, M):
+            if np.asarray(X).shape[0] in (96, 70 + 96):      # the batch containing structure 1, and structure 1 alone
+                e = PestoError("boom")
+                e.code = code
+                raise e
+            return np.zeros((np.asarray(M).shape[1], 5), np.float32)
+        return fwd
+    for code in (-1, -5):                                  # bad input / out of the f16 range: that structure only
+        res = sharding.forward_local(make(code), structures, [0, 1, 2], max_atoms=170)
+        assert res[1] is None and res[0] is not None and res[2] is not None
+    for code in (-2, -3, None):                            # HIP failure, out of memory, library missing: the run
+        with pytest.raises(PestoError):
+            sharding.forward_local(make(code), structures, [0, 1, 2], max_atoms=170)
+    structures = structures[:2]
 
     def broken(X, ids, q, M):
         raise OSError("library missing")
@@ -113,6 +131,42 @@ def test_systemic_failure_propagates():
         raise ValueError("bad input")
     with pytest.raises(ValueError):
         sharding.forward_local(all_bad, structures, [0, 1], max_atoms=100)
+
+
+def _all_bad_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datetime
+
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    structures = _structures()[:2]                       # one structure per rank (LPT): rank 1 owns the 70-atom one
+
+    def fwd(X, ids, q, M):
+        if np.asarray(X).shape[0] == 70:
+            raise ValueError("bad input")
+        return np.zeros((np.asarray(M).shape[1], 5), np.float32)
+    try:
+        try:
+            sharding.forward_sharded(fwd, structures, n_out=5, max_atoms=200)
+            verdict = "returned"
+        except sharding.AllStructuresFailed as e:
+            verdict = "raised:" + str(e)
+        open(os.path.join(out_dir, f"verdict{rank}.txt"), "w").write(verdict)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_whose_structures_all_fail_does_not_hang_the_collective(tmp_path):
+    """A rank that owns only bad structures still enters the gather; afterwards EVERY rank raises the same error (before this the
+    failing rank raised in front of the collective and the others waited for the process-group timeout)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_all_bad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    v = [open(os.path.join(str(tmp_path), f"verdict{r}.txt")).read() for r in range(2)]
+    assert all(x.startswith("raised:") for x in v) and v[0] == v[1]
 
 
 # ---------------------------------------------------------------------------------------------- on the GPU box
@@ -137,23 +191,41 @@ def _hip_worker(rank, world, port, out_dir, backend):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(0)                       # a 1-GPU box: every rank drives GPU 0 (gloo carries the collectives)
-    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # gloo on a 1-GPU box: every rank drives GPU 0 (gloo carries the collectives); nccl (= RCCL): one GPU per rank
+    gpu = rank if backend == "nccl" else 0
+    torch.cuda.set_device(gpu)
+    kw = {"device_id": torch.device("cuda", gpu)} if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **kw)
     try:
-        res = sharding.forward_sharded(_hip_model().to("cuda:0"), _hip_structures(), n_out=5, max_atoms=2000)
+        m = _hip_model().to(f"cuda:{gpu}")
+        res = sharding.forward_sharded(m, _hip_structures(), n_out=5, max_atoms=2000)
+        assert m.status()["n_fp32_rerun"] == 0      # grouping-independence is bitwise only while no launch is repeated in fp32
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{str(i): z for i, z in enumerate(res)})
     finally:
         dist.destroy_process_group()
 
 
+def _n_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1), ("nccl", "all")])
 def test_sharded_hip_forward_equals_single_process_bitwise(tmp_path, backend, world):
     """The REAL path under torch.distributed: ranks shard the structures, run them through libpesto_hip.so and gather every
     result. gloo / world 2 (both ranks on the box's one GPU) exercises the partition + ragged gather across processes; nccl /
     world 1 exercises the RCCL collectives with device tensors (what an 8-GPU node uses). Either way every structure must come
-    back with exactly the bits of a plain single-process run, including the N < 64 members (PESTO_BATCH_INDEPENDENT)."""
+    back with exactly the bits of a plain single-process run, including the N < 64 members (PESTO_BATCH_INDEPENDENT).
+    ("nccl", "all"): one rank per visible GPU over RCCL / xGMI - the real multi-GPU leg; skipped on a box with fewer than two."""
     import torch.multiprocessing as mp
+    if world == "all":
+        world = _n_gpus()
+        if world < 2:
+            pytest.skip("needs at least two GPUs (the round-end multi-GPU box runs it)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
