@@ -255,6 +255,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="testing only: every rank uses GPU 0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
+    ap.add_argument("--edge-mode", type=int, default=0, help="developer: pesto_debug_edge_mode (0 = per launch, 1 rendezvous, 2 node waves, 3 32-edge tiles)")
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="atom numbering of the synthetic clouds: generation order, or along a Z-order curve")
     args = ap.parse_args()
@@ -290,6 +291,8 @@ def main():
     sd, wdesc = load_weights(config)
     model = Model(config, validate=False, precision=args.precision).to(dev)
     model.load_state_dict(sd)
+    if args.edge_mode:
+        model.debug_edge_mode(args.edge_mode)
 
     # ---- inputs: one batch per rank, resident in HBM before the timed region
     X, ids, q, roa, R = make_batch(args.atoms, args.batch, 1000 * rank + 1, n0, args.order)

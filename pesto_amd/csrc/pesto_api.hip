@@ -397,7 +397,7 @@ int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_
 
 int pesto_debug_edge_mode(pesto_model* m, int32_t mode) {
     if (check_model(m)) return PESTO_ERR_INVALID;
-    if (mode < 0 || mode > 2) return fail(PESTO_ERR_INVALID, "mode must be 0 (per launch), 1 (rendezvous) or 2 (node waves)");
+    if (mode < 0 || mode > 3) return fail(PESTO_ERR_INVALID, "mode must be 0 (per launch), 1 (rendezvous), 2 (node waves) or 3 (32-edge tiles)");
     m->edge_mode = mode;
     return 0;
 }

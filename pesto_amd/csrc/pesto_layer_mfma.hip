@@ -28,6 +28,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "pesto_kernels.h"
 
@@ -540,17 +541,32 @@ __device__ __forceinline__ float row_reduce(float x) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // =============================================================================================== edge kernel
-#ifdef PESTO_PROFILE_PHASES   // developer build: per-phase wave cycles (s_memtime), printed by pesto_destroy
+#if defined(PESTO_TRACE32)      // developer build: timeline of ONE wave (block 0, wave 0), no per-phase accumulators (they cost registers)
+__device__ unsigned long long g_trace32[4096];
+__device__ __forceinline__ void trace32(int& n, int id) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n < 4096) g_trace32[n++] = ((unsigned long long)id << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull);
+}
+#define PHASE_MARK(k) trace32(tr_n, 30 + (k))
+#define PHASE_INIT() do {} while (0)
+#define PHASE_DECL() do {} while (0)
+#define PHASE_FLUSH() do {} while (0)
+#define TRACE32(id) trace32(tr_n, id)
+#define P32_MARK(k) trace32(tr_n, k)
+#elif defined(PESTO_PROFILE_PHASES)   // developer build: per-phase wave cycles (s_memtime), printed by pesto_destroy
 __device__ unsigned long long g_phase_cycles[12];
 #define PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); phase_acc_[k] += now_ - tmark_; tmark_ = now_; } while (0)
 #define PHASE_INIT() tmark_ = __builtin_readcyclecounter()
 #define PHASE_DECL() unsigned long long tmark_ = 0, phase_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PHASE_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_phase_cycles[k_], phase_acc_[k_]); } while (0)
+#define TRACE32(id) do {} while (0)
+#define P32_MARK(k) do {} while (0)
 #else
 #define PHASE_MARK(k) do {} while (0)
 #define PHASE_INIT() do {} while (0)
 #define PHASE_DECL() do {} while (0)
 #define PHASE_FLUSH() do {} while (0)
+#define TRACE32(id) do {} while (0)
+#define P32_MARK(k) do {} while (0)
 #endif
 struct alignas(16) EdgeWaveScratch {      // 16-byte multiple: the rows are read / written as float4 (ds_read / ds_write_b128)
     int nb[64];          // neighbour id per row
@@ -559,6 +575,16 @@ struct alignas(16) EdgeWaveScratch {      // 16-byte multiple: the rows are read
     float wsum[8][2];    // per centre: sum over edges of the part-2 weights (multiplies p_i)
     float z3buf[2][2][96];  // [centre sel][h][c*32+s]: sum_e w3[h][e] p_j(e), staged for the final combine
 };
+// per-wave scratch of the 32-edge-tile kernel (M32, further down)
+struct alignas(16) EdgeWaveScratch32 {
+    int nb[64];               // neighbour id per row of the work item
+    float geo[4][64];         // r_hat x, y, z, d per row
+    float stage[32 * 36];     // 32 edges x 9 units of 16 B: the p_j . r operands, then the A_j chunks of a tile (aliased in time);
+                              // at the end of a centre the first 384 floats hold the p_j sums [slot][h][96]
+    float wt[10][32];         // unnormalised attention weights of the current tile: rows h: scalar; 2 + 3 h + c: part 1 x r_c; 8 + h: part 3
+    float stat[2][2][4];      // [centre slot][h]: 1 / s_scalar, 1 / s_vector, (sum of the part-2 weights) / s_vector
+};
+constexpr int ST32 = 36;      // floats per edge row of the staging area (9 units: an odd stride spreads 16 consecutive rows over all banks)
 // offsets of the NEXT layer's prepare tables (the [U|A], G and nqm fragments / biases of LayerW): the finishing waves of the edge
 // kernel write that layer's centre / neighbour records right behind the state update (k_node16's prepare half, same arithmetic)
 struct PrepW { int32_t h_ua, h_gc, h_n0, n_b1s, n_bn0, n_bn1, n_bn2; };
@@ -569,11 +595,11 @@ constexpr int XCH_FLOATS = 3072;
 // NE < WPB ("node waves"): the other WPB - NE waves ONLY finish / prepare, fed through LDS queues without any workgroup barrier:
 // two generations of staged Z rows per edge wave and of the 16-centre state exchange.
 constexpr int XF_POST = 0, XF_READY = 2, XF_CONSUMED = 4;      // xflag slots: slices posted per tile | rows staged per generation | generations read
-template <int WPB, bool HY, bool XCH = false, int NE = WPB>
+template <int WPB, bool HY, bool XCH = false, int NE = WPB, bool M32 = false>
 struct EdgeSmem {
     static constexpr int GEN = (XCH && NE < WPB) ? 2 : 1;
-    float w[HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS];
-    EdgeWaveScratch ws[NE];
+    float w[M32 ? EDGE_LDS_FLOATS_32 : HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS];
+    typename std::conditional<M32, EdgeWaveScratch32, EdgeWaveScratch>::type ws[NE];
     float zrows[NE][GEN][2][256];   // Zq | Zp staging per centre: two rows per edge wave (and generation)
     float xch[XCH ? (NE < WPB ? 2 * 2048 : XCH_FLOATS) : 4];
     int xflag[8];        // monotone counters (see XF_*)
@@ -742,6 +768,562 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
     }
 }
 
+// =============================================================================================== 32-edge tiles (M32)
+// The same layer on v_mfma_f32_32x32x16_f16: one MFMA covers 32 edges x 32 features. Why (profiles/microbench/r03_shadow.txt): next
+// to the 4-pass 16x16x32 instruction almost nothing else issues (its cost and the cost of every VALU instruction simply add up),
+// while the 8-pass 32x32x16 one takes the same time per FLOP and hides ~5 VALU instructions each; a weight fragment read from LDS
+// feeds twice as many edges. What the wider tile changes:
+//   * ONE pass per tile: keys, logits, a tile-local softmax (unnormalised weights e = exp(l - m); for nn = 64 the running maximum of
+//     the centre's two tiles with the usual rescaling of the partial sums), values, weighted sums; the normalisation 1 / sum is applied
+//     once per centre at the end. The gathers (A_j, p_j) and p_j . r are done once per edge, not once per pass.
+//   * Gathers stay in a producer lane layout (consecutive lanes read consecutive 16-byte pieces of one atom's record, few cache lines
+//     per quarter-wave) and reach the MFMA operand layout (lane = edge) through a 4.5 KB LDS staging area per wave (ds_write_b128 /
+//     ds_read_b128, rows of 9 x 16 B: conflict-free both ways) - ds_bpermute cannot fill a 32-edge operand from 16-edge producer rounds.
+//   * A_j is read from the staging area straight into the accumulators (no add); the centre terms U_i + sum_c r_c G_i[c] AND the distance
+//     term w_d d are ONE extra K = 16 MFMA per 32 features: A = (G0 G1 G2 U)(hi) (G0 G1 G2 U)(lo) | (G0 G1 G2 U)(hi) (wd_hi wd_lo wd_hi 0),
+//     B = (rx ry rz 1)(hi) x 2 | (rx ry rz 0)(lo) (d_hi d_hi d_lo 0) - the three products of the hi/lo split.
+// D tile: lane (n = l & 31, hl = l >> 5), register v <-> row 8 (v >> 2) + 4 hl + (v & 3), column n. Registers [8 ks .. 8 ks + 7] of a D
+// tile are the B (or A) operand of k-step ks of the next layer; the weight fragments are laid out to match (pesto_schema.h, EL32_*).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+
+__device__ __forceinline__ f32x4 bufld4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float bufld1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float bufld1s(__amdgpu_buffer_rsrc_t r, int byte_off, int s_off) {      // s_off: wave-uniform (SGPR) part
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, s_off, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0xfffffffc, 0x00020000);
+}
+// op(x[l], x[l ^ 16]) / op(x[l], x[l ^ 32]) on the VALU (gfx950 lane swaps; both operands are the same value)
+template <int CTRL>
+__device__ __forceinline__ float dpp_bc(float x) {      // DPP source with bound_ctrl (no `old` value: the compiler folds it into the consumer)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// v_permlane16_swap / v_permlane32_swap exchange rows (halves) BETWEEN two registers; with a copy of x in the second register the two
+// results are x and x[l ^ 16] (x[l ^ 32]) in some order, so a symmetric op needs no select. Inline asm (validated in
+// profiles/microbench/permlane_test.hip): the compiler's builtin returned the same register for both results here. Only called on values
+// produced by VALU code after this wave's last MFMA result has been read (no matrix instruction of the wave is in flight).
+template <bool IS_MAX>
+__device__ __forceinline__ float xrow(float x) {
+    float a = x, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    return IS_MAX ? fmaxf(a, b) : a + b;
+}
+template <bool IS_MAX>
+__device__ __forceinline__ float xhalf(float x) {
+    float a = x, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    return IS_MAX ? fmaxf(a, b) : a + b;
+}
+// reduction over the lanes of one centre inside a 32-lane half (16 lanes for nn = 16, the whole half otherwise)
+template <int NN, bool IS_MAX>
+__device__ __forceinline__ float centre_reduce(float x) {
+    x = row_reduce<true, IS_MAX>(x);
+    if (NN >= 32) x = xrow<IS_MAX>(x);
+    return x;
+}
+__device__ __forceinline__ unsigned pack_h2(float lo, float hi) {      // (f16(lo) | f16(hi) << 16), round to nearest
+    const f32x2 x = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+}
+// x -> packed (hi pair, lo pair) of two values: hi = rn16(x), lo = rn16(x - hi)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2 x = {a, b};
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    float m1 = -1.0f;
+    asm("" : "+s"(m1));
+    f16x2 l;
+    l[0] = (_Float16)__builtin_fmaf((float)h[0], m1, a);
+    l[1] = (_Float16)__builtin_fmaf((float)h[1], m1, b);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ f16x8 frag32(const float* tab, int idx, int lane) { return ld8h(tab + idx * 256 + lane * 4); }
+
+#ifdef PESTO_DEBUG32     // developer build: intermediates of the work item that holds centre g_dbg32_centre
+__device__ float g_dbg32[4096];
+__device__ int g_dbg32_centre = 5;
+#define DBG32(idx, val) do { if (dbg_) g_dbg32[(idx)] = (val); } while (0)
+#else
+#define DBG32(idx, val) do {} while (0)
+#endif
+// One work item (TI/2 tiles of 32 edges = A whole centres) of the M32 kernel. Leaves the complete Z rows of its centres in zrow[slot].
+template <int NN, int T32>
+__device__ __forceinline__ void edge_item32(EdgeWaveScratch32& ws, const float* __restrict__ smw, float (*zrow)[256], int sub, int lane_in,
+                                            int c0, int N1, __amdgpu_buffer_rsrc_t r_nb, __amdgpu_buffer_rsrc_t r_cen, __amdgpu_buffer_rsrc_t r_p,
+                                            float inv_sdk, float& sat, int& tr_n) {
+    constexpr int CPT = NN == 16 ? 2 : 1;            // centres per tile
+    constexpr int NCS = NN == 16 ? 2 : 1;            // accumulator sets per lane (centres whose edges one lane's V registers cover)
+    constexpr float L2E = 1.44269504088896340736f;
+    // sum / max over the lanes of one centre inside a 32-lane half: four DPP steps inside the arithmetic instruction (v_add_f32_dpp; the max
+    // as inline v_max_f32_dpp - the compiler's fmaxf canonicalises both operands first: three instructions per step) + one row swap
+    auto csum = [](float x) {
+        x += dpp_bc<0xB1>(x); x += dpp_bc<0x4E>(x); x += dpp_bc<0x141>(x); x += dpp_bc<0x140>(x);
+        if (NN >= 32) x = xrow<false>(x);
+        return x;
+    };
+    auto cmax = [](float x) {
+        asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1" : "+v"(x));
+        if (NN >= 32) x = xrow<true>(x);
+        return x;
+    };
+#ifdef PESTO_DEBUG32
+    const bool dbg_ = g_dbg32_centre >= c0 && g_dbg32_centre < c0 + 16 * 2 * T32 / NN;
+#endif
+    // running state of a centre that spans two tiles (nn = 64): maxima, sums, partial Z (rescaled when the maximum moves)
+    float run_ms[2] = {0.f, 0.f}, run_mv[2] = {0.f, 0.f};
+    float S_s[2] = {0.f, 0.f}, S_v[2] = {0.f, 0.f}, W2[2] = {0.f, 0.f};
+    float zq[NCS][2], zp1[NCS][2][3];
+    f32x4 z3[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { zq[cs][h] = 0.f; zp1[cs][h][0] = zp1[cs][h][1] = zp1[cs][h][2] = 0.f; }
+    float p_own[NCS][3];                      // the centre's own p (second block of Vp, model_operations.py:133), feature n
+    // (prefetching the next tile's p_j rows into registers - all 48 behind the first value layer, all 48 or only the first round of 24
+    // at the end of the tile - makes the register allocator spill in the hot loop: nn = 64 275 -> 330-340 us per launch,
+    // profiles/r03_m32_ab.txt; the loads are therefore issued at the top of their own tile)
+
+#pragma unroll 1
+    for (int t = 0; t < T32; ++t) {
+        const int row0 = 32 * t;
+        // (the lane-derived addresses of the gathers are re-derived per tile from an opaque copy of the lane index: hoisted out of
+        // the tile loop as loop invariants they occupy thirty registers for the whole item)
+        int lane_o = lane_in;
+        asm volatile("" : "+v"(lane_o));
+        const int lane = lane_o, n = lane & 31, hl = lane >> 5, n_o = n, hl_o = hl;
+        const int esub = lane / 24, quad = lane - 24 * esub, es = esub == 2 ? 0 : esub;     // p_j sums: lane = (edge half, 16-byte piece of the 96-vector)
+        // centre of column n of this tile
+        const int cen_i = min(c0 + (NN == 64 ? 0 : NN == 32 ? t : (n_o >> 4)), N1 - 1);
+        const int cen_off = cen_i * (REC_CEN * 4);
+        // ------------------------------------------------------------------ gathers of the tile
+        int aj_off[4];       // A_j: lane = 8 * edge + 16-byte piece of the 128-byte chunk of one 32-feature block; 8 edges per load
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aj_off[i] = ws.nb[row0 + 8 * i + (lane_o >> 3)] * (REC_A * 4) + 16 * (lane_o & 7);
+        f32x4 aj[2][4];      // two chunks in flight (blocks 0, 1 now; 2, 3 during the key networks)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aj[k][i] = bufld4(r_nb, aj_off[i] + 128 * k);
+        // centre records: (G0, G1, G2, U) of feature 32 rb + n for every centre of the tile (rows of the centre MFMA's A operand):
+        // one lane-dependent address, the block / piece as immediate offsets, the centre as the wave-uniform offset
+        float cg[CPT][4][4];
+        const int cg_lane = ((n_o >> 4) * 64 + (n_o & 15)) * 4;
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) {
+            const int co = __builtin_amdgcn_readfirstlane(min(c0 + (NN == 64 ? 0 : NN == 32 ? t : cc), N1 - 1) * (REC_CEN * 4));
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) cg[cc][rb][kg] = bufld1s(r_cen, cg_lane + (2 * rb * 64 + kg * 16) * 4, co);
+        }
+        float QA[6], QV[6];                   // QA: queries of this lane's first key group (scalar for hl = 0, vector for hl = 1); QV: vector
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { QA[j] = bufld1(r_cen, cen_off + (512 + 6 * hl_o + j) * 4); QV[j] = bufld1(r_cen, cen_off + (518 + j) * 4); }
+        if (t % (NN == 64 ? 2 : 1) == 0) {
+#pragma unroll
+            for (int cs = 0; cs < NCS; ++cs) {
+                const int ci = min(c0 + (NN == 32 ? t : cs), N1 - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p_own[cs][c] = bufld1(r_p, ci * 384 + (c * 32 + n_o) * 4);
+            }
+        }
+        P32_MARK(0);
+        // ------------------------------------------------------------------ geometry operand of the centre MFMA
+        const float gx = ws.geo[0][row0 + n], gy = ws.geo[1][row0 + n], gz = ws.geo[2][row0 + n], gd = ws.geo[3][row0 + n];
+        u32x4 bcen[CPT];
+        {
+            unsigned hxy, lxy, hz1, lz0, hd, ld;
+            split2(gx, gy, hxy, lxy);
+            split2(gz, gd, hz1, lz0);           // (rz_hi | d_hi), (rz_lo | d_lo)
+            hd = hz1 >> 16; ld = lz0 >> 16;
+            const unsigned one = 0x3c00u;       // 1.0 in f16
+            const unsigned rz1 = (hz1 & 0xffffu) | (one << 16);
+            u32x4 b;
+            if (hl == 0) b = u32x4{hxy, rz1, hxy, rz1};
+            else b = u32x4{lxy, lz0 & 0xffffu, hd | (hd << 16), ld};
+            if (NN == 16) {      // two centres per tile: each centre's MFMA sees only its own 16 columns
+                const u32x4 zero = u32x4{0, 0, 0, 0};
+                bcen[0] = n < 16 ? b : zero; bcen[CPT - 1] = n < 16 ? zero : b;
+            } else {
+                bcen[0] = b;
+            }
+        }
+        // ------------------------------------------------------------------ p_j . r_hat (model_operations.py:115) -> f16 hi/lo -> staging
+        {
+            f32x4 pj[2][6];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int off = ws.nb[row0 + 16 * r + (lane_o >> 2)] * 384 + 32 * (lane_o & 3);
+                pj[r][0] = bufld4(r_p, off); pj[r][1] = bufld4(r_p, off + 16);
+                pj[r][2] = bufld4(r_p, off + 128); pj[r][3] = bufld4(r_p, off + 144);
+                pj[r][4] = bufld4(r_p, off + 256); pj[r][5] = bufld4(r_p, off + 272);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int e = 16 * r + (lane_o >> 2);
+                const float rx = ws.geo[0][row0 + e], ry = ws.geo[1][row0 + e], rz = ws.geo[2][row0 + e];
+                const f32x4 a = pj[r][0] * rx + pj[r][2] * ry + pj[r][4] * rz;
+                const f32x4 b = pj[r][1] * rx + pj[r][3] * ry + pj[r][5] * rz;
+                f16x8 fh, fl;
+                split8(a, b, fh, fl);
+                float* dst = ws.stage + e * ST32 + 8 * (lane_o & 3);
+                *reinterpret_cast<f16x8*>(dst) = fh;
+                *reinterpret_cast<f16x8*>(dst + 4) = fl;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        f16x8 prh[2], prl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* src = ws.stage + n * ST32 + 8 * (2 * ks + hl);
+            prh[ks] = ld8h(src); prl[ks] = ld8h(src + 4);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // first layer of two 32-feature blocks rb0, rb0 + 1: accumulators start as A_j (staging), centre MFMA, W1P MFMAs, ELU, split
+        f16x8 h1h[2][2], h1l[2][2];
+        auto layer1_pair = [&](auto RB0) {
+            constexpr int rb0 = decltype(RB0)::value;
+            f32x16 acc[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int rb = rb0 + k;
+                // A_j chunk of this block: producer lanes -> staging -> accumulator registers
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st4(ws.stage + (8 * i + (lane >> 3)) * ST32 + 4 * (lane & 7), aj[k][i]);
+                __builtin_amdgcn_wave_barrier();
+                if (rb0 == 0) {      // the chunks of blocks 2, 3 fly during the key networks
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) aj[k][i] = bufld4(r_nb, aj_off[i] + 128 * (rb + 2));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = ld4(ws.stage + n * ST32 + 4 * (2 * q + hl));
+                    acc[k][4 * q] = v[0]; acc[k][4 * q + 1] = v[1]; acc[k][4 * q + 2] = v[2]; acc[k][4 * q + 3] = v[3];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // centre operands: (G0 G1 G2 U) hi, then lo (hl = 0) or the distance weights (hl = 1)
+#pragma unroll
+            for (int cc = 0; cc < CPT; ++cc) {
+                u32x4 acen[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int rb = rb0 + k;
+                    unsigned h01, l01, h2u, l2u;
+                    split2(cg[cc][rb][0], cg[cc][rb][1], h01, l01);
+                    split2(cg[cc][rb][2], cg[cc][rb][3], h2u, l2u);
+                    if (hl == 1) {
+                        const float* wd = smw + EL32_WD + 2 * (32 * rb + n);
+                        l01 = __builtin_bit_cast(unsigned, wd[0]); l2u = __builtin_bit_cast(unsigned, wd[1]);
+                    }
+                    acen[k] = u32x4{h01, h2u, l01, l2u};
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) acc[k] = MFMA32(__builtin_bit_cast(f16x8, acen[k]), __builtin_bit_cast(f16x8, bcen[cc]), acc[k]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 wh[2], wl[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { wh[k] = frag32(smw + EL32_W1P, ((rb0 + k) * 2 + ks) * 2, lane); wl[k] = frag32(smw + EL32_W1P, ((rb0 + k) * 2 + ks) * 2 + 1, lane); }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) acc[k] = MFMA32(wh[k], prh[ks], acc[k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) acc[k] = MFMA32(wh[k], prl[ks], acc[k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) acc[k] = MFMA32(wl[k], prh[ks], acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                sat_probe(sat, acc[k][0]);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f32x4 u0 = elu4s(f32x4{acc[k][8 * ks], acc[k][8 * ks + 1], acc[k][8 * ks + 2], acc[k][8 * ks + 3]});
+                    const f32x4 u1 = elu4s(f32x4{acc[k][8 * ks + 4], acc[k][8 * ks + 5], acc[k][8 * ks + 6], acc[k][8 * ks + 7]});
+                    split8(u0, u1, h1h[k][ks], h1l[k][ks]);
+                }
+            }
+        };
+        layer1_pair(std::integral_constant<int, 0>{});
+        P32_MARK(2);
+        // ------------------------------------------------------------------ key networks (eqkm | epkm layers 2, 3) -> logits
+        float la[2], lb[2];
+        {
+            f32x16 a2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = ld4(smw + EL32_B2 + 32 * k + 4 * (2 * q + hl));
+                    a2[k][4 * q] = v[0]; a2[k][4 * q + 1] = v[1]; a2[k][4 * q + 2] = v[2]; a2[k][4 * q + 3] = v[3];
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 wh[2], wl[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { wh[k] = frag32(smw + (k ? EL32_W2EP : EL32_W2EQ), ks * 2, lane); wl[k] = frag32(smw + (k ? EL32_W2EP : EL32_W2EQ), ks * 2 + 1, lane); }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) a2[k] = MFMA32(wh[k], h1h[k][ks], a2[k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) a2[k] = MFMA32(wh[k], h1l[k][ks], a2[k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) a2[k] = MFMA32(wl[k], h1h[k][ks], a2[k]);
+            }
+            f16x8 h2h[2][2], h2l[2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                sat_probe(sat, a2[k][0]);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f32x4 u0 = elu4s(f32x4{a2[k][8 * ks], a2[k][8 * ks + 1], a2[k][8 * ks + 2], a2[k][8 * ks + 3]});
+                    const f32x4 u1 = elu4s(f32x4{a2[k][8 * ks + 4], a2[k][8 * ks + 5], a2[k][8 * ks + 6], a2[k][8 * ks + 7]});
+                    split8(u0, u1, h2h[k][ks], h2l[k][ks]);
+                }
+            }
+            // keys: rows 4 part + kappa, K = [eq h2 | ep h2]: two partial accumulators (the eq and the ep half), summed
+            f32x16 ka[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = ld4(smw + EL32_BK + 4 * (2 * q + hl));
+                ka[0][4 * q] = v[0]; ka[0][4 * q + 1] = v[1]; ka[0][4 * q + 2] = v[2]; ka[0][4 * q + 3] = v[3];
+                ka[1][4 * q] = 0.f; ka[1][4 * q + 1] = 0.f; ka[1][4 * q + 2] = 0.f; ka[1][4 * q + 3] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 wh[2], wl[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { wh[k] = frag32(smw + EL32_W3K, (2 * k + ks) * 2, lane); wl[k] = frag32(smw + EL32_W3K, (2 * k + ks) * 2 + 1, lane); }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) ka[k] = MFMA32(wh[k], h2h[k][ks], ka[k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) ka[k] = MFMA32(wh[k], h2l[k][ks], ka[k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) ka[k] = MFMA32(wl[k], h2h[k][ks], ka[k]);
+            }
+            // lane (n, hl): registers 0..2 = key of part hl, 4..6 = key of part 2 + hl (kappa = 0..2) of edge n
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                la[h] = (QA[3 * h] * (ka[0][0] + ka[1][0]) + QA[3 * h + 1] * (ka[0][1] + ka[1][1]) + QA[3 * h + 2] * (ka[0][2] + ka[1][2])) * inv_sdk;
+                lb[h] = (QV[3 * h] * (ka[0][4] + ka[1][4]) + QV[3 * h + 1] * (ka[0][5] + ka[1][5]) + QV[3 * h + 2] * (ka[0][6] + ka[1][6])) * inv_sdk;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { DBG32((t * 8 + h) * 64 + lane, la[h]); DBG32((t * 8 + 2 + h) * 64 + lane, lb[h]); }
+        // ------------------------------------------------------------------ softmax of the tile (:139-140), unnormalised weights
+        // scalar: part 0 (hl = 0, la); vector: parts 1 (hl = 1, la), 2 (hl = 0, lb), 3 (hl = 1, lb) share one softmax over 3 nn slots
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float mA = cmax(la[h]), mB = cmax(lb[h]);
+            float mv = xhalf<true>(hl ? fmaxf(mA, mB) : mB);
+            float ms = mA;                                     // (meaningful on the hl = 0 lanes)
+            if (NN == 64) {
+                ms = lane_bcast(mA, 0);                        // one centre per wave: wave-uniform
+                if (t > 0) {
+                    const float nms = fmaxf(run_ms[h], ms), nmv = fmaxf(run_mv[h], mv);
+                    const float as = __builtin_amdgcn_exp2f((run_ms[h] - nms) * L2E), av = __builtin_amdgcn_exp2f((run_mv[h] - nmv) * L2E);
+                    zq[0][h] *= as; S_s[h] *= as;
+                    zp1[0][h][0] *= av; zp1[0][h][1] *= av; zp1[0][h][2] *= av; z3[h] *= av; S_v[h] *= av; W2[h] *= av;
+                    ms = nms; mv = nmv;
+                }
+                run_ms[h] = ms; run_mv[h] = mv;
+            }
+            const float ea = __builtin_amdgcn_exp2f((la[h] - (hl ? mv : ms)) * L2E);
+            const float eb = __builtin_amdgcn_exp2f((lb[h] - mv) * L2E);
+            const float sA = csum(ea), sB = csum(eb);
+            const float sv = xhalf<false>(hl ? sA + sB : sB);
+            if (NN == 64) { S_s[h] += sA; S_v[h] += sv; W2[h] += sB; }
+            else { S_s[h] = sA; S_v[h] = sv; W2[h] = sB; }
+            DBG32((t * 8 + 4 + h) * 64 + lane, ea); DBG32((t * 8 + 6 + h) * 64 + lane, eb);
+            if (hl == 0) {
+                ws.wt[h][n] = ea;
+            } else {
+                ws.wt[2 + 3 * h][n] = ea * gx; ws.wt[3 + 3 * h][n] = ea * gy; ws.wt[4 + 3 * h][n] = ea * gz;
+                ws.wt[8 + h][n] = eb;
+            }
+        }
+        // statistics of the centres that end with this tile: written by the first lane of the centre (hl = 0 holds s_scalar and the part-2 sum)
+        if ((NN != 64 || t == T32 - 1) && hl == 0 && (n & (NN == 16 ? 15 : 31)) == 0) {
+            const int slot = NN == 64 ? 0 : NN == 32 ? t : (n >> 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float iv = __builtin_amdgcn_rcpf(S_v[h]);
+                ws.stat[slot][h][0] = __builtin_amdgcn_rcpf(S_s[h]); ws.stat[slot][h][1] = iv; ws.stat[slot][h][2] = W2[h] * iv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        P32_MARK(4);
+        // ------------------------------------------------------------------ p_j sums, first half of the tile's edges issued now
+        f32x4 pv[8];
+        {
+            const u32x4 nb4a = *reinterpret_cast<const u32x4*>(&ws.nb[row0 + 16 * es]), nb4b = *reinterpret_cast<const u32x4*>(&ws.nb[row0 + 16 * es + 4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pv[i] = bufld4(r_p, (int)nb4a[i] * 384 + 16 * quad); pv[4 + i] = bufld4(r_p, (int)nb4b[i] * 384 + 16 * quad); }
+        }
+        // ------------------------------------------------------------------ value network (evm), first layer blocks 2, 3
+        f16x8 vh[2][2], vl[2][2];
+        {
+            // (h1h / h1l are reused for the value half)
+            layer1_pair(std::integral_constant<int, 2>{});
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) { vh[k][ks] = h1h[k][ks]; vl[k][ks] = h1l[k][ks]; }
+        }
+
+        f32x16 a2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = ld4(smw + EL32_B2 + 64 + 32 * k + 4 * (2 * q + hl));
+                a2[k][4 * q] = v[0]; a2[k][4 * q + 1] = v[1]; a2[k][4 * q + 2] = v[2]; a2[k][4 * q + 3] = v[3];
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {       // k-steps of the 64 inputs: block kk >> 1, step kk & 1
+            f16x8 wh[2], wl[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { wh[k] = frag32(smw + EL32_W2EV, (k * 4 + kk) * 2, lane); wl[k] = frag32(smw + EL32_W2EV, (k * 4 + kk) * 2 + 1, lane); }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) a2[k] = MFMA32(wh[k], vh[kk >> 1][kk & 1], a2[k]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) a2[k] = MFMA32(wh[k], vl[kk >> 1][kk & 1], a2[k]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) a2[k] = MFMA32(wl[k], vh[kk >> 1][kk & 1], a2[k]);
+        }
+        P32_MARK(6);
+        // first half of the p_j sums (their loads had the first two value layers to land)
+        {
+            const float* w3a = &ws.wt[8][16 * es], *w3b = &ws.wt[9][16 * es];
+            const f32x4 wa0 = ld4(w3a), wa1 = ld4(w3a + 4), wb0 = ld4(w3b), wb1 = ld4(w3b + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { z3[0] += wa0[i] * pv[i]; z3[1] += wb0[i] * pv[i]; z3[0] += wa1[i] * pv[4 + i]; z3[1] += wb1[i] * pv[4 + i]; }
+            const u32x4 nb4a = *reinterpret_cast<const u32x4*>(&ws.nb[row0 + 16 * es + 8]), nb4b = *reinterpret_cast<const u32x4*>(&ws.nb[row0 + 16 * es + 12]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pv[i] = bufld4(r_p, (int)nb4a[i] * 384 + 16 * quad); pv[4 + i] = bufld4(r_p, (int)nb4b[i] * 384 + 16 * quad); }
+        }
+        f16x8 g2h[2][2], g2l[2][2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            sat_probe(sat, a2[k][0]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f32x4 u0 = elu4s(f32x4{a2[k][8 * ks], a2[k][8 * ks + 1], a2[k][8 * ks + 2], a2[k][8 * ks + 3]});
+                const f32x4 u1 = elu4s(f32x4{a2[k][8 * ks + 4], a2[k][8 * ks + 5], a2[k][8 * ks + 6], a2[k][8 * ks + 7]});
+                split8(u0, u1, g2h[k][ks], g2l[k][ks]);
+            }
+        }
+        // values V[edge][feature]: edges are the MFMA rows (A operand = h2), weights the B operand; column block 0 = q values, 1 = p values
+        f32x16 vv[2];
+        {
+            const float bp = smw[EL32_B3V + 32 + n];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { vv[0][i] = 0.f; vv[1][i] = bp; }      // (the q block's bias is added after the normalisation: its weights sum to 1)
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f16x8 bh[2], bl[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) { bh[cb] = frag32(smw + EL32_W3V, (cb * 4 + kk) * 2, lane); bl[cb] = frag32(smw + EL32_W3V, (cb * 4 + kk) * 2 + 1, lane); }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) vv[cb] = MFMA32(g2h[kk >> 1][kk & 1], bh[cb], vv[cb]);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) vv[cb] = MFMA32(g2l[kk >> 1][kk & 1], bh[cb], vv[cb]);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) vv[cb] = MFMA32(g2h[kk >> 1][kk & 1], bl[cb], vv[cb]);
+        }
+        // second half of the p_j sums
+        {
+            const float* w3a = &ws.wt[8][16 * es + 8], *w3b = &ws.wt[9][16 * es + 8];
+            const f32x4 wa0 = ld4(w3a), wa1 = ld4(w3a + 4), wb0 = ld4(w3b), wb1 = ld4(w3b + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { z3[0] += wa0[i] * pv[i]; z3[1] += wb0[i] * pv[i]; z3[0] += wa1[i] * pv[4 + i]; z3[1] += wb1[i] * pv[4 + i]; }
+        }
+        // attention-weighted sums over this lane's sixteen edges (registers 4 q + r <-> edge 8 q + 4 hl + r)  (:143-144, first block of Vp :132)
+        // one weight row at a time: its four LDS reads (the lane's sixteen edges; broadcast within a half) are issued one row ahead
+        {
+            f32x4 wr[2][4];
+            auto load_row = [&](int row, f32x4* dst) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = ld4(&ws.wt[row][8 * q + 4 * hl]);
+            };
+            load_row(0, wr[0]);
+#pragma unroll
+            for (int row = 0; row < 8; ++row) {       // rows 0, 1: scalar weights of head 0, 1 (q values); 2 + 3 h + c: part-1 weights x r_c (p values)
+                if (row < 7) load_row(row + 1, wr[(row + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4* w = wr[row & 1];
+                const int cb = row < 2 ? 0 : 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cs = NN == 16 ? (q >> 1) : 0;
+                    float& z = row < 2 ? zq[cs][row] : zp1[cs][(row - 2) / 3][(row - 2) % 3];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z = __builtin_fmaf(w[q][r], vv[cb][4 * q + r], z);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        P32_MARK(9);
+        if (NN == 64 && t == 0) continue;      // the centre continues in the second tile
+        // ------------------------------------------------------------------ centre(s) complete: combine, normalise, stage the Z rows
+        {   // p_j sums -> staging area [slot][h][96] (nn = 16: the two edge halves ARE the two centres; otherwise fold them)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (NN != 16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z3[h][j] += __shfl_down(z3[h][j], 24);
+                }
+                if (NN == 16 ? lane < 48 : esub == 0) st4(ws.stage + ((NN == 16 ? es : 0) * 2 + h) * 96 + 4 * quad, z3[h]);
+                z3[h] = f32x4{0, 0, 0, 0};
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int cs = 0; cs < NCS; ++cs) {
+            const int slot = NN == 64 ? sub : NN == 32 ? t : cs;       // staged row of this centre (FIN)
+            const int sslot = NN == 64 ? 0 : NN == 32 ? t : cs;        // where its statistics are
+            float* zb = zrow[slot];
+            // totals over the two lane halves; this lane then finishes head h = hl
+            float tq[2], tp[2][3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                tq[h] = xhalf<false>(zq[cs][h]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tp[h][c] = xhalf<false>(zp1[cs][h][c]);
+                zq[cs][h] = 0.f; zp1[cs][h][0] = zp1[cs][h][1] = zp1[cs][h][2] = 0.f;
+            }
+            const f32x4 st = ld4(&ws.stat[sslot][hl][0]);
+            DBG32(1024 + 4 * lane, st[0]); DBG32(1024 + 4 * lane + 1, st[1]); DBG32(1024 + 4 * lane + 2, st[2]); DBG32(1024 + 4 * lane + 3, (float)cs);
+            DBG32(1280 + cs * 512 + lane, tq[0]); DBG32(1280 + cs * 512 + 64 + lane, tq[1]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { DBG32(1280 + cs * 512 + 128 + c * 64 + lane, tp[0][c]); DBG32(1280 + cs * 512 + 320 + c * 64 + lane, p_own[cs][c]); }
+            const float q_own = hl ? tq[1] : tq[0];
+            zb[hl * 32 + n] = q_own * st[0] + smw[EL32_B3V + n];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float p_sum = hl ? tp[1][c] : tp[0][c];
+                zb[64 + c * 64 + hl * 32 + n] = (p_sum + ws.stage[((NN == 16 ? cs : 0) * 2 + hl) * 96 + c * 32 + n]) * st[1] + st[2] * p_own[cs][c];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#ifdef PESTO_DEBUG32
+        if (dbg_) for (int cs = 0; cs < NCS; ++cs) for (int k = lane; k < 256; k += 64) g_dbg32[2304 + cs * 256 + k] = zrow[NN == 64 ? sub : NN == 32 ? t : cs][k];
+#endif
+        P32_MARK(10);
+    }
+}
+
 // WPB = waves per workgroup: 4 (exact fp32 path: two workgroups per CU, 2 waves/SIMD, explicit cross-tile prefetch PF)
 // or 12 / 8 (f16-split path: one workgroup per CU, 3 / 2 waves per SIMD sharing one LDS copy of the layer constants).
 // FIN (finish in the edge kernel): the attention sums Z of a centre never leave the CU. Every wave leaves the complete Z rows of
@@ -749,7 +1331,7 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
 // the matrix cores - role 0: q += qpm(Zq), roles 1..3: p[c] += ppm(Zp[c]) (model_operations.py:147-152), sink reset (:239-240) -
 // with the weight fragments streamed from L2, and write the NEW state into the other half of a ping-pong pair (neighbours'
 // p_j of the old state are still being gathered by other workgroups). The node kernel then only prepares records.
-template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4, bool FIN = false, int NE = WPB>
+template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4, bool FIN = false, int NE = WPB, bool M32 = false>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
                                                  const float* __restrict__ rec_nb, const float* rec_cen,
@@ -771,12 +1353,13 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     constexpr int SUBS = FIN ? 2 / A : 1;
     constexpr bool NODEW = FIN && NE < WPB;      // node-wave mode: waves NE.. finish / prepare only
     static_assert(NE == WPB || (FIN && WPB - NE == 4 && NE * A * SUBS == 16), "node waves: four of them, one 16-centre tile per iteration");
-    __shared__ EdgeSmem<WPB, HY, FIN, NE> sm;
+    static_assert(!M32 || (FIN && HY && NE == WPB && WPB == 8 && NN >= 16 && TI % 2 == 0), "M32: eight-wave rendezvous workgroups, whole 32-edge tiles");
+    __shared__ EdgeSmem<WPB, HY, FIN, NE, M32> sm;
     if (threadIdx.x < 8) sm.xflag[threadIdx.x] = 0;
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
-        const f32x4* src = reinterpret_cast<const f32x4*>(W + (F16 ? lw.e_lds16 : lw.e_lds));
+        const f32x4* src = reinterpret_cast<const f32x4*>(W + (M32 ? lw.e_lds32 : F16 ? lw.e_lds16 : lw.e_lds));
         f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
-        for (int k = threadIdx.x; k < (HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS) / 4; k += WPB * 64) dst[k] = src[k];
+        for (int k = threadIdx.x; k < (M32 ? EDGE_LDS_FLOATS_32 : HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS) / 4; k += WPB * 64) dst[k] = src[k];
     }
     __syncthreads();
     const float* w2f = sm.w + EL_W2F;
@@ -791,6 +1374,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     const int chunk = (n_work + 7) >> 3;
     const int w_end = min(n_work, (xcd + 1) * chunk);
     PHASE_DECL();
+    int tr_n = 0;           // (developer builds: timeline of one wave)
+    (void)tr_n;
     float sat = 0.0f;       // range guard of the f16-split path (sat_probe)
     int fin_iter = 0;       // finish phases done (FIN)
     // the trip count is the same for every wave of a workgroup (FIN: workgroup barriers inside); a wave without a work item idles
@@ -807,7 +1392,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
       const int lane = tid_i & 63, wave = tid_i >> 6;
       const int e = lane & 15, g = lane >> 4;
       const int wslot = (NODEW && wave >= NE) ? 0 : wave;      // (node waves never touch the per-wave scratch)
-      EdgeWaveScratch& ws = sm.ws[wslot];
+      auto& ws = sm.ws[wslot];
       float (*zrow)[256] = sm.zrows[wslot][NODEW ? (fin_iter & 1) : 0];
       const bool tail = w_end - it_start < nbx * NE * SUBS;
       const int sstride = tail ? nbx * NE : NE;
@@ -819,6 +1404,24 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
       const int work = base + sub * sstride + wave;
       if (work < w_end && (!NODEW || wave < NE)) {
         const int c0 = work * A;
+        if constexpr (M32) {
+            TRACE32(19);
+            {   // rows of this work item: lane = row
+                const int a = lane / NN, c = lane % NN, i = c0 + a;
+                const bool valid = i < N1 && lane < 16 * TI;
+                const size_t src = (size_t)min(i, N1 - 1) * KMAX + c;
+                const int nbv = ids_s[src];
+                const float4 gg = geo[src];
+                ws.nb[lane] = valid ? nbv : 0;
+                ws.geo[0][lane] = valid ? gg.x : 0.f; ws.geo[1][lane] = valid ? gg.y : 0.f; ws.geo[2][lane] = valid ? gg.z : 0.f;
+                ws.geo[3][lane] = valid ? gg.w : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            PHASE_INIT();
+            TRACE32(20);
+            edge_item32<NN, TI / 2>(ws, sm.w, zrow, sub, lane, c0, N1, make_rsrc(rec_nb), make_rsrc(rec_cen), make_rsrc(p_state), inv_sdk, sat, tr_n);
+            PHASE_MARK(1);
+        } else {
         PHASE_INIT();
         {   // rows of this work item: lane = row
             const int a = lane / NN, c = lane % NN, i = c0 + a;
@@ -1281,6 +1884,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             __builtin_amdgcn_wave_barrier();
             PHASE_MARK(6);
         }
+        }   // !M32
       }   // work item
       }   // sub
       if (FIN && !NODEW) {
@@ -1783,8 +2387,22 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     PHASE_FLUSH();
 }
 
+#ifdef PESTO_DEBUG32
+extern "C" int pesto_debug_dump32(float* out, int centre) {
+    if (centre >= 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg32_centre), &centre, sizeof(int));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg32), sizeof(float) * 4096);
+}
+#endif
 void debug_print_phase_cycles() {
-#ifdef PESTO_PROFILE_PHASES
+#ifdef PESTO_TRACE32
+    static unsigned long long tr[4096];
+    if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace32), sizeof tr) == hipSuccess && tr[0]) {
+        fprintf(stderr, "[pesto trace32] id:delta_cycles of block 0 wave 0 (last launch that traced):");
+        for (int k = 1; k < 400 && tr[k]; ++k) fprintf(stderr, " %d:%lld", (int)(tr[k] >> 56), (long long)((tr[k] & 0xffffffffffffffull) - (tr[k - 1] & 0xffffffffffffffull)));
+        fprintf(stderr, "\n");
+    }
+#endif
+#if defined(PESTO_PROFILE_PHASES) && !defined(PESTO_TRACE32)
     unsigned long long h[12];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_cycles), sizeof h) == hipSuccess) {
         const char* names[12] = {"setup", "pass1(keys)", "softmax", "p2:L1+L2", "p2:L3(values)", "p2:accumulate", "p2:finalize", "fin:issue", "fin:barrier1",
@@ -1820,14 +2438,14 @@ struct EdgeIO {     // per-launch pointers of the edge kernel
     PrepW prep; float* rec_nb_out; float* rec_cen_out;     // FIN only: the next layer's tables and record buffers (null: no prepare phase)
 };
 
-template <int NN, int WPB, bool PF, bool F16, bool HY, int TI, bool FIN = false, int NE = WPB>
+template <int NN, int WPB, bool PF, bool F16, bool HY, int TI, bool FIN = false, int NE = WPB, bool M32 = false>
 static void launch_edge_k(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks) {
     constexpr int A = 16 * TI / NN;
     const int n_work = (N1 + A - 1) / A;
     int blocks = ((n_work + 7) / 8 + NE - 1) / NE * 8;     // per-XCD share of the work items, NE (item-processing waves) per workgroup, x 8 XCDs
     if (blocks > max_blocks) blocks = max_blocks / 8 * 8;
     if (blocks < 8) blocks = 8;
-    hipLaunchKernelGGL((k_edge<NN, WPB, PF, F16, HY, TI, FIN, NE>), dim3(blocks), dim3(WPB * 64), 0, st, W, lw, N1, n_work, io.ids_s, io.geo, io.rec_nb,
+    hipLaunchKernelGGL((k_edge<NN, WPB, PF, F16, HY, TI, FIN, NE, M32>), dim3(blocks), dim3(WPB * 64), 0, st, W, lw, N1, n_work, io.ids_s, io.geo, io.rec_nb,
                        io.rec_cen, io.p_state, io.Z, io.flags, io.q_state, io.q_out, io.p_out, io.prep, io.rec_nb_out, io.rec_cen_out);
 }
 
@@ -1877,7 +2495,19 @@ static bool node_wave_mode(int nn, int n_work) {
     const double cost = nn == 8 ? 0.90 : nn == 16 ? 0.965 : nn == 32 ? 1.0 : 1.023;
     return rounds_paid(n_work, 8, subs) * cost < rounds_paid(n_work, 12, subs);
 }
+// M32: the 32-edge-tile kernel (v_mfma_f32_32x32x16_f16, eight-wave rendezvous workgroups); its gathers use 32-bit buffer offsets
+constexpr int M32_MAX_ATOMS = 2000000;      // N1 * REC_CEN * 4 bytes must stay below 2^32
+static bool launch_edge_m32(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks) {
+    if (N1 > M32_MAX_ATOMS) return false;
+    switch (lw.nn) {
+        case 16: launch_edge_k<16, 8, false, true, true, 2, true, 8, true>(st, W, lw, N1, io, max_blocks); return true;
+        case 32: launch_edge_k<32, 8, false, true, true, 4, true, 8, true>(st, W, lw, N1, io, max_blocks); return true;
+        case 64: launch_edge_k<64, 8, false, true, true, 4, true, 8, true>(st, W, lw, N1, io, max_blocks); return true;
+        default: return false;
+    }
+}
 static void launch_edge_full(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks, int mode) {
+    if (mode == 3 && launch_edge_m32(st, W, lw, N1, io, max_blocks)) return;
     const int a = lw.nn == 64 ? 1 : 2;                                     // centres per 64-row item (nn = 8: one-tile items of two centres)
     const bool nw = mode == 0 ? node_wave_mode(lw.nn, (N1 + a - 1) / a) : mode == 2;
     switch (lw.nn) {

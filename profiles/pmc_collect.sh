@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
 mkdir -p $R/gpurun_out/pmc_$TAG
-CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-latency --no-extras --precision f16_split"
+CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-latency --no-extras --precision f16_split ${PESTO_BENCH_ARGS:-}"      # PESTO_BENCH_ARGS: e.g. "--edge-mode 3"
 i=0
 for SET in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
