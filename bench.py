@@ -212,10 +212,12 @@ def config4_leg(model, dist, backend, dev, n_structures, reps, max_atoms):
     ok = all(g is not None and np.array_equal(g, local[i]) for i, g in enumerate(gathered))
     t_med = float(np.median(times))
     return {"workload": f"{len(structures)} synthetic structures with the pdbs_test size histogram ({min(sizes)}-{max(sizes)} atoms, "
-                        f"{sum(sizes)} atoms in total), i_v4_1, fixed list sharded over {world} rank(s) by atom count (LPT), launches of <= "
-                        f"{max_atoms} atoms, inputs in HOST memory (H2D inside the timed region), logits all-gathered to every rank "
+                        f"{sum(sizes)} atoms in total), i_v4_1, list sharded over {world} rank(s) by atom count (LPT), launches of <= "
+                        f"{max_atoms} atoms, inputs in HOST memory (packing + H2D inside the timed region, two launches in flight: "
+                        f"pesto_forward_batch_submit / _wait), logits all-gathered to every rank "
                         f"({backend if world > 1 else 'no collective at world 1'})",
-            "structures": len(structures), "value": len(structures) / t_med, "unit": "structures/s", "scaling": "strong",
+            "structures": len(structures), "structures_per_rank": len(structures) // world, "value": len(structures) / t_med, "unit": "structures/s",
+            "scaling": "weak (the list grows with the world size: a fixed number of structures per rank)",
             "seconds_per_pass_median": t_med, "passes": reps, "bitwise_equal_to_world1": bool(ok)}
 
 
@@ -251,7 +253,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency side measurement")
     ap.add_argument("--no-check", action="store_true", help="developer ablation builds only: do not check the timed output")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 and config-4 legs (profiling runs)")
-    ap.add_argument("--config4-structures", type=int, default=64)
+    ap.add_argument("--config4-structures", type=int, default=64, help="structures PER RANK of the config-4 leg (the list has this many x world size)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="testing only: every rank uses GPU 0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
@@ -491,7 +493,7 @@ def main():
     # ---- BASELINE config 4 as a strong-scaling leg (every world size runs the same list)
     cfg4 = None
     if (not args.no_extras or args.mode == "strong") and args.config == "i_v4_1":
-        cfg4 = config4_leg(model, dist, args.backend, dev, args.config4_structures, max(3, min(args.steps, 5)), 24576)
+        cfg4 = config4_leg(model, dist, args.backend, dev, args.config4_structures * world, max(3, min(args.steps, 5)), 24576)
 
     if rank == 0:
         n_struct = args.steps * args.batch * world

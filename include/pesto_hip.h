@@ -67,7 +67,7 @@ typedef struct pesto_config {
 typedef struct pesto_model pesto_model;
 
 enum { PESTO_PTR_HOST = 0, PESTO_PTR_DEVICE = 1 };
-enum { PESTO_IDS_INT32 = 32, PESTO_IDS_INT64 = 64 };
+enum { PESTO_IDS_INT32 = 32, PESTO_IDS_INT64 = 64, PESTO_IDS_UINT16 = 16 /* pesto_forward_batch_submit only */ };
 
 const char* pesto_last_error(void);
 
@@ -142,6 +142,26 @@ enum { PESTO_BATCH_COLLATED = 0, PESTO_BATCH_INDEPENDENT = 1 };
 int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, const int64_t* R, const int32_t* k,
                         const float* const* X, const void* const* ids_topk0, int32_t ids_kind, const float* const* q0,
                         const int32_t* const* res_of_atom, float* const* z_out, int32_t batch_mode, void* stream);
+
+/* replaces: the same bulk loop fed by DataLoader(num_workers = 8) (interfaceome/apply_model.py:50-82; SURVEY 8b, threading row: "host may
+ * overlap H2D of structure t+1 with compute of t"). pesto_forward_batch in two halves, with TWO staging slots per handle:
+ *   submit  packs the structures into the slot's PINNED host buffer, queues one H2D copy on the handle's copy stream and - behind it, on
+ *           the handle's compute stream - the collate kernel, the forward and the D2H copy of the logits into pinned memory; returns at
+ *           once with the slot as *ticket. A second submit may follow before the first is waited for: its packing and H2D copy overlap
+ *           the first launch's kernels (PESTO_ERR_STATE if both slots are in flight).
+ *   wait    blocks until the ticket's logits have arrived, reports bad inputs (PESTO_ERR_INVALID) / handles the range guard as
+ *           pesto_forward_batch does (AUTO: the slot's inputs are still on the device, the launch is repeated on the fp32 kernels),
+ *           and copies the logits into the z_out[b] arrays given at submit (which must stay valid until then; the input arrays may be
+ *           reused as soon as submit returns).
+ * Inputs as pesto_forward_batch, plus two compact forms that cut the H2D volume from 392 to 145 bytes per atom:
+ *   ids_kind PESTO_IDS_UINT16  ids_topk0[b] as uint16 (0-based within the structure, N_b <= 65,536);
+ *   q_index != NULL            instead of the dense one-hot q0[b]: uint8 [N_b, n_index] block-local indices, expanded on the GPU to
+ *                              q0[i][index_offsets[c] + q_index[i][c]] = 1 (encode_features, src/data_encoding.py:78-84). */
+int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* N, const int64_t* R, const int32_t* k,
+                               const float* const* X, const void* const* ids_topk0, int32_t ids_kind,
+                               const float* const* q0, const uint8_t* const* q_index, int32_t n_index, const int32_t* index_offsets,
+                               const int32_t* const* res_of_atom, float* const* z_out, int32_t batch_mode, int32_t* ticket);
+int pesto_forward_batch_wait(pesto_model* m, int32_t ticket);
 
 /* bytes of device workspace a batch of (N, R) needs (ownership: SURVEY 8b) */
 int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* bytes);

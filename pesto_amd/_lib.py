@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PESTO_LIB") or os.path.join(_HERE, "csrc", "libpesto_hip.so")   # PESTO_LIB: developer builds
 
 PTR_HOST, PTR_DEVICE = 0, 1
-IDS_INT32, IDS_INT64 = 32, 64
+IDS_INT32, IDS_INT64, IDS_UINT16 = 32, 64, 16
 BATCH_COLLATED, BATCH_INDEPENDENT = 0, 1
 # enum pesto_precision
 PRECISIONS = {"auto": 0, "f16_split": 1, "fp32": 2}
@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "pesto_stage_embed", "pesto_stage_unpack", "pesto_stage_layer", "pesto_stage_pool", "pesto_knn_collate",
     "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch", "pesto_get_kernel_timing",
     "pesto_set_precision", "pesto_get_status", "pesto_debug_select", "pesto_forward_structures",
-    "pesto_mask_to_segments", "pesto_debug_edge_mode",
+    "pesto_mask_to_segments", "pesto_debug_edge_mode", "pesto_forward_batch_submit", "pesto_forward_batch_wait",
 ]
 
 _lib = None
@@ -99,6 +99,8 @@ def load():
     lib.pesto_forward_structures.argtypes = [c_p, i64, i64, i32, i32, c_p, c_p, c_p, i32, c_p, c_p, c_p, i32, c_p]
     lib.pesto_forward_frames.argtypes = [c_p, i64, i64, i32, i64, c_p, i64, i64, c_p, i32, c_p, c_p, c_p, i32, i32, c_p]
     lib.pesto_forward_batch.argtypes = [c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p, c_p, i32, c_p]
+    lib.pesto_forward_batch_submit.argtypes = [c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, i32, P(i32)]
+    lib.pesto_forward_batch_wait.argtypes = [c_p, i32]
     lib.pesto_set_precision.argtypes = [c_p, i32]
     lib.pesto_get_status.argtypes = [c_p, P(i32), P(i64), P(i64)]
     lib.pesto_debug_select.argtypes = [c_p, i32, i32]

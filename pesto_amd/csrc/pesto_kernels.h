@@ -44,6 +44,8 @@ int knn_cells_per_struct();
 // seg_of_atom [n_total] / seg_end [n_struct]: structure index of every atom and the end offset of every structure (for launch_unpack)
 void launch_collate(hipStream_t st, int n_total, int n_struct, const void* meta, const void* ids_raw, int ids_kind, const int* roa_raw,
                     int* ids_out, int* roa_out, int* seg_of_atom, int* seg_end, int* err_flag);
+// q0 [N, n0] one-hot from n_idx (1..3) byte index columns per atom; offs[c] = first feature of block c
+void launch_onehot(hipStream_t st, int N, int n0, int n_idx, const unsigned char* idx, const int* offs, float* q0, int* err_flag);
 void launch_segments(hipStream_t st, int n_total, int n_struct, const int* seg_end, int* seg_of_atom);
 // dense mask M [N,R] -> roa [N] (column of the single member per row, -1 for rows with != 1 member; roa[0] = -1 if a column is empty);
 // seen: R ints of scratch

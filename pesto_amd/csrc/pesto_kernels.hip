@@ -846,9 +846,34 @@ void launch_collate(hipStream_t st, int n_total, int n_struct, const void* meta,
     if (ids_kind == PESTO_IDS_INT64)
         hipLaunchKernelGGL(k_collate<long long>, grid, block, 0, st, n_total, n_struct, (const CollateMeta*)meta, (const long long*)ids_raw, roa_raw,
                            ids_out, roa_out, seg_of_atom, seg_end, err_flag);
+    else if (ids_kind == PESTO_IDS_UINT16)
+        hipLaunchKernelGGL(k_collate<unsigned short>, grid, block, 0, st, n_total, n_struct, (const CollateMeta*)meta, (const unsigned short*)ids_raw,
+                           roa_raw, ids_out, roa_out, seg_of_atom, seg_end, err_flag);
     else
         hipLaunchKernelGGL(k_collate<int>, grid, block, 0, st, n_total, n_struct, (const CollateMeta*)meta, (const int*)ids_raw, roa_raw, ids_out,
                            roa_out, seg_of_atom, seg_end, err_flag);
+}
+
+// One-hot features from their indices: q0[i][offs[c] + idx[i][c]] = 1 for the n_idx index columns of atom i (encode_features,
+// src/data_encoding.py:78-84: element | residue name | atom name blocks), everything else 0. One thread per output float.
+// An index outside its block sets the ids error bit (the forward then reports bad inputs).
+__global__ __launch_bounds__(256) void k_onehot(int N, int n0, int n_idx, const unsigned char* __restrict__ idx, int o0, int o1, int o2,
+                                                float* __restrict__ q0, int* __restrict__ err_flag) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)N * n0) return;
+    const int i = (int)(e / n0), f = (int)(e - (int64_t)i * n0);
+    const int offs[4] = {o0, o1, o2, n0};
+    float v = 0.0f;
+    for (int c = 0; c < n_idx; ++c) {
+        const int hit = offs[c] + idx[(size_t)i * n_idx + c];
+        if (hit >= (c + 1 < n_idx ? offs[c + 1] : n0)) atomicOr(err_flag, 1);
+        if (hit == f) v = 1.0f;
+    }
+    q0[e] = v;
+}
+void launch_onehot(hipStream_t st, int N, int n0, int n_idx, const unsigned char* idx, const int* offs, float* q0, int* err_flag) {
+    hipLaunchKernelGGL(k_onehot, dim3((unsigned)(((int64_t)N * n0 + 255) / 256)), dim3(256), 0, st, N, n0, n_idx, idx, offs[0], n_idx > 1 ? offs[1] : n0,
+                       n_idx > 2 ? offs[2] : n0, q0, err_flag);
 }
 
 // ------------------------------------------------------------------------------------------------ post-processing

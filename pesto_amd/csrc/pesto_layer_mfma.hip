@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     constexpr int SUBS = FIN ? 2 / A : 1;
     constexpr bool NODEW = FIN && NE < WPB;      // node-wave mode: waves NE.. finish / prepare only
     static_assert(NE == WPB || (FIN && WPB - NE == 4 && NE * A * SUBS == 16), "node waves: four of them, one 16-centre tile per iteration");
-    static_assert(!M32 || (FIN && HY && NE == WPB && WPB == 8 && NN >= 16 && TI % 2 == 0), "M32: eight-wave rendezvous workgroups, whole 32-edge tiles");
+    static_assert(!M32 || (HY && NE == WPB && WPB == 8 && NN >= 16 && TI % 2 == 0), "M32: eight-wave workgroups, whole 32-edge tiles");
     __shared__ EdgeSmem<WPB, HY, FIN, NE, M32> sm;
     if (threadIdx.x < 8) sm.xflag[threadIdx.x] = 0;
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
@@ -1421,6 +1421,18 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             TRACE32(20);
             edge_item32<NN, TI / 2>(ws, sm.w, zrow, sub, lane, c0, N1, make_rsrc(rec_nb), make_rsrc(rec_cen), make_rsrc(p_state), inv_sdk, sat, tr_n);
             PHASE_MARK(1);
+            if (!FIN) {      // unfused variant: the Z rows of the item's centres go to memory, the node kernel applies the output MLPs
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    const int i = c0 + a;
+                    if (i < N1) {
+                        float* zo = Z + (size_t)i * REC_Z;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) zo[lane + 64 * k] = zrow[a][lane + 64 * k];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         } else {
         PHASE_INIT();
         {   // rows of this work item: lane = row
@@ -2506,6 +2518,15 @@ static bool launch_edge_m32(hipStream_t st, const float* W, const LayerW& lw, in
         default: return false;
     }
 }
+static bool launch_edge_m32_unfused(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks) {
+    if (N1 > M32_MAX_ATOMS) return false;
+    switch (lw.nn) {
+        case 16: launch_edge_k<16, 8, false, true, true, 2, false, 8, true>(st, W, lw, N1, io, max_blocks); return true;
+        case 32: launch_edge_k<32, 8, false, true, true, 4, false, 8, true>(st, W, lw, N1, io, max_blocks); return true;
+        case 64: launch_edge_k<64, 8, false, true, true, 4, false, 8, true>(st, W, lw, N1, io, max_blocks); return true;
+        default: return false;
+    }
+}
 static void launch_edge_full(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks, int mode) {
     if (mode == 3 && launch_edge_m32(st, W, lw, N1, io, max_blocks)) return;
     const int a = lw.nn == 64 ? 1 : 2;                                     // centres per 64-row item (nn = 8: one-tile items of two centres)
@@ -2540,6 +2561,9 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
     const int n_work = (N1 + 64 / lw.nn - 1) / (64 / lw.nn);
     if (variant == 1) {
         launch_edge_t<4, true, false>(st, W, lw, N1, io, max_blocks);
+    } else if (q_out == nullptr) {
+        // unfused f16-split layer (developer mode 4): Z through memory, k_node16 finishes; 32-edge tiles where they exist
+        if (!launch_edge_m32_unfused(st, W, lw, N1, io, 256)) launch_edge_t<12, false, true, true>(st, W, lw, N1, io, 256);
     } else {
         // (the finish phase always runs inside the shipped kernel: q_out / p_out are required)
         // fine work items (one centre each for nn >= 16): when they outnumber the 2,048 wave slots of eight-wave workgroups, twelve

@@ -299,6 +299,74 @@ class Model:
                                            _lib.BATCH_INDEPENDENT if independent else _lib.BATCH_COLLATED, None))
         return zs
 
+    # ------------------------------------------------------------------ pipelined launches (SURVEY 8b threading row)
+    ONEHOT_OFFSETS = {30: (0,), 123: (0, 30, 59)}       # feature blocks of encode_features (src/data_encoding.py:78-84): element | resname | atom name
+
+    def forward_batch_submit(self, structures, independent=True, compact=True):
+        """First half of forward_batch (pesto_forward_batch_submit): packs the structures into a pinned staging slot and queues the
+        H2D copy, the forward and the D2H copy; returns a ticket at once. Up to two tickets may be in flight, so the packing and the copy
+        of launch t + 1 overlap the kernels of launch t (the reference feeds its loop from DataLoader workers the same way,
+        interfaceome/apply_model.py:50-82). ``compact``: neighbour ids as uint16 and - when q0 is one-hot in the reference's feature
+        blocks - features as byte indices (145 instead of 392 bytes per atom over PCIe; expanded on the GPU, same bits)."""
+        h = self._ensure()
+        lib = _lib.load()
+        n0, n_out = self.config["em"]["N0"], self.config["dm"]["N2"]
+        nb = len(structures)
+        if nb < 1:
+            raise ValueError("no structures")
+        offs = self.ONEHOT_OFFSETS.get(n0)
+        arr = lambda ct: (ct * nb)()
+        Np, Rp, kp = arr(ctypes.c_int64), arr(ctypes.c_int64), arr(ctypes.c_int32)
+        Xp, Ip, Qp, Jp, Ap, Zp = (arr(ctypes.c_void_p) for _ in range(6))
+        zs, keep = [], []
+        use_idx = compact and offs is not None
+        id_dtype = np.uint16 if compact and all(int(np.shape(s[0])[0]) <= 65536 for s in structures) else np.int32
+        for b, (X, ids, q0, M) in enumerate(structures):
+            roa, R = mask_to_segments(M) if self.validate else (np.asarray(M.detach().cpu().numpy() if _is_torch(M) else M).argmax(1).astype(np.int32), int(M.shape[1]))
+            Xn = np.ascontiguousarray(X.detach().cpu().numpy() if _is_torch(X) else X, dtype=np.float32)
+            idn = np.ascontiguousarray((ids.detach().cpu().numpy() if _is_torch(ids) else np.asarray(ids)).astype(id_dtype, copy=False))
+            qn = np.ascontiguousarray(q0.detach().cpu().numpy() if _is_torch(q0) else q0, dtype=np.float32)
+            roa = np.ascontiguousarray(roa, dtype=np.int32)
+            N = Xn.shape[0]
+            if idn.ndim != 2 or idn.shape[0] != N:
+                raise ValueError(f"structure {b}: ids_topk must be [N, k] with N={N}")
+            self._check_shapes(N, Xn.shape, qn.shape, roa.shape, n0)
+            qi = None
+            if use_idx:      # one-hot rows -> block-local byte indices (exactly one 1 per block, else fall back to the dense form)
+                bounds = list(offs) + [n0]
+                cols = [qn[:, bounds[c]:bounds[c + 1]] for c in range(len(offs))]
+                if all(np.array_equal(c.sum(1), np.ones(N, np.float32)) and np.array_equal(c.max(1), np.ones(N, np.float32)) for c in cols):
+                    qi = np.ascontiguousarray(np.stack([c.argmax(1) for c in cols], 1).astype(np.uint8))
+                else:
+                    use_idx = False
+                    for kb in keep:
+                        kb[4] = None
+            z = np.empty((R, n_out), dtype=np.float32)
+            keep.append([Xn, idn, qn, roa, qi])
+            zs.append(z)
+            Np[b], Rp[b], kp[b] = N, R, idn.shape[1]
+            Xp[b], Ip[b], Qp[b], Ap[b], Zp[b] = Xn.ctypes.data, idn.ctypes.data, qn.ctypes.data, roa.ctypes.data, z.ctypes.data
+        if use_idx:
+            for b, kb in enumerate(keep):
+                Jp[b] = kb[4].ctypes.data
+        io = (ctypes.c_int32 * 3)(*(list(offs) + [0] * (3 - len(offs)))) if use_idx else None
+        kind = {np.dtype(np.uint16): _lib.IDS_UINT16, np.dtype(np.int32): _lib.IDS_INT32}[np.dtype(id_dtype)]
+        t = ctypes.c_int32(-1)
+        _lib.check(lib.pesto_forward_batch_submit(h, nb, Np, Rp, kp, Xp, Ip, kind, None if use_idx else Qp, Jp if use_idx else None,
+                                                  len(offs) if use_idx else 0, io, Ap, Zp,
+                                                  _lib.BATCH_INDEPENDENT if independent else _lib.BATCH_COLLATED, ctypes.byref(t)))
+        self._tickets = getattr(self, "_tickets", {})
+        self._tickets[t.value] = zs          # the logits arrays must stay alive until the wait (the packed inputs need not)
+        return t.value
+
+    def forward_batch_wait(self, ticket):
+        """Second half: blocks until the launch behind ``ticket`` has finished and returns its [z_b] (numpy)."""
+        zs = getattr(self, "_tickets", {}).pop(ticket, None)
+        if zs is None:
+            raise ValueError(f"no launch in flight under ticket {ticket}")
+        _lib.check(_lib.load().pesto_forward_batch_wait(self._ensure(), ticket))
+        return zs
+
     # ------------------------------------------------------------------ trajectory frames (SURVEY 8f row 3)
     def forward_frames(self, X_frames, ids_topk, q0, M, frame_axis=0, frames_per_launch=0):
         """z [F, R, N2] for F coordinate frames of the same atoms with ONE topology: what the reference's MD loop

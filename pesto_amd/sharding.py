@@ -107,7 +107,43 @@ def forward_local(forward_fn, structures, indices, max_atoms=24576, raise_if_all
             r0 += r
 
     last_error = None
-    for group in batches(indices, sizes, max_atoms):
+    groups = batches(indices, sizes, max_atoms)
+    # a pesto_amd.Model: two launches in flight (submit t + 1 while t computes: host packing and the H2D copy overlap the kernels)
+    pipelined = hasattr(forward_fn, "forward_batch_submit")
+    pending = None      # (group, ticket) of the launch in flight
+
+    def finish(p):
+        g, t = p
+        for i, z in zip(g, forward_fn.forward_batch_wait(t)):
+            results[i] = np.ascontiguousarray(z)
+
+    if pipelined:
+        todo = []       # groups whose pipelined launch failed: rerun below on the synchronous path with its per-structure handling
+        for group in groups:
+            try:
+                ticket = forward_fn.forward_batch_submit([tuple(structures[i]) for i in group], independent=True)
+            except Exception as e:
+                if not _is_skippable(e):
+                    raise
+                todo.append(group)
+                continue
+            if pending is not None:
+                try:
+                    finish(pending)
+                except Exception as e:
+                    if not _is_skippable(e):
+                        raise
+                    todo.append(pending[0])
+            pending = (group, ticket)
+        if pending is not None:
+            try:
+                finish(pending)
+            except Exception as e:
+                if not _is_skippable(e):
+                    raise
+                todo.append(pending[0])
+        groups = todo
+    for group in groups:
         try:
             run(group)
         except Exception as e_group:

@@ -762,7 +762,7 @@ def test_forward_golden_forced_edge_modes_agree_bitwise(fixture):
     g = golden(fixture)
     roa = g["res_of_atom"]
     zs = []
-    for mode in (1, 2, 3):
+    for mode in (1, 2, 3, 4):
         m = _model("i_v4_0", "mfma").debug_edge_mode(mode)
         z = m.forward_segments(g["X"], g["ids_topk"].astype(np.int64), onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
         assert np.abs(z - g["z"]).max() < 1e-4
@@ -853,3 +853,51 @@ def test_mask_to_segments_kernel_and_the_reference_signature():
     assert rc == -1 and b"atom 11" in lib.pesto_last_error()
     rc = lib.pesto_mask_to_segments(m.handle, roa.size, R, M.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), _lib.PTR_HOST, None)
     assert rc == 0 and np.array_equal(out, roa)
+
+
+# ---------------------------------------------------------------------------------------------- pipelined launches (submit / wait)
+def test_forward_batch_submit_wait_equals_forward_batch_bitwise():
+    """pesto_forward_batch_submit / _wait: two launches in flight, the compact input forms (uint16 neighbour ids, byte feature
+    indices expanded on the GPU) and the plain ones - every structure must come back with the bits of pesto_forward_batch; a bad
+    structure is reported by the wait of ITS ticket and the handle survives."""
+    from pesto_amd._lib import PestoError
+    from pesto_amd.topology import synthetic_structure
+    m = _model("i_v4_0", "mfma")
+    groups = [[synthetic_structure(n, 500 + 10 * g + i, n0=30) for i, n in enumerate(sizes)] for g, sizes in enumerate(((700, 90, 300), (40, 1200), (64, 65, 500)))]
+    ref = [m.forward_batch(g, independent=True) for g in groups]
+    for compact in (True, False):
+        t0 = m.forward_batch_submit(groups[0], compact=compact)
+        t1 = m.forward_batch_submit(groups[1], compact=compact)          # second launch queued while the first runs
+        with pytest.raises(PestoError):
+            m.forward_batch_submit(groups[2], compact=compact)           # both slots in flight
+        z0 = m.forward_batch_wait(t0)
+        t2 = m.forward_batch_submit(groups[2], compact=compact)
+        z1, z2 = m.forward_batch_wait(t1), m.forward_batch_wait(t2)
+        for got, want in zip((z0, z1, z2), ref):
+            assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    # i_v3_0: three one-hot blocks (30 + 29 + 64 features) through the byte-index form
+    m3 = _model("i_v3_0", "mfma")
+    g3 = [synthetic_structure(n, 900 + n, n0=123) for n in (300, 150)]
+    want = m3.forward_batch(g3, independent=True)
+    got = m3.forward_batch_wait(m3.forward_batch_submit(g3))
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    # a bad neighbour index: the error belongs to that ticket, the other launch and the handle are unaffected
+    bad = [list(s) for s in groups[1]]
+    bad[0][1] = bad[0][1].copy(); bad[0][1][3, 2] = 4000
+    tb = m.forward_batch_submit([tuple(s) for s in bad])
+    tg = m.forward_batch_submit(groups[0])
+    with pytest.raises(PestoError):
+        m.forward_batch_wait(tb)
+    assert all(np.array_equal(a, b) for a, b in zip(m.forward_batch_wait(tg), ref[0]))
+    with pytest.raises(ValueError):
+        m.forward_batch_wait(tg)                                         # already collected
+
+
+def test_sharding_forward_local_pipelined_equals_one_call_per_structure():
+    from pesto_amd.sharding import forward_local
+    from pesto_amd.topology import synthetic_structure
+    m = _model("i_v4_0", "mfma")
+    structs = [synthetic_structure(n, 640 + i, n0=30) for i, n in enumerate((300, 180, 96, 700, 64, 1500, 20))]
+    res = forward_local(m, structs, list(range(len(structs))), max_atoms=800)       # several launches, two in flight
+    for i, st in enumerate(structs):
+        assert np.array_equal(res[i], m.forward_batch([st], independent=True)[0])
