@@ -71,6 +71,11 @@ struct pesto_model {
     hipStream_t ws_stream = nullptr;
     bool ws_pending = false;
     int* h_flags = nullptr;                // pinned host copy of the flags word (read back without a pageable staging copy)
+    // PESTO_PRECISION_AUTO with device pointers stays asynchronous: the flags word of the launch is copied to h_flags[8] behind it and
+    // looked at by the NEXT call on the handle (resolve_pending): bad inputs are reported there, a range overflow repeats the
+    // remembered launch on the exact fp32 kernels (its buffers must still be valid) and makes the handle run fp32 first from then on
+    struct Pending { bool active = false; hipStream_t st = nullptr; hipEvent_t ev = nullptr; void* args = nullptr; } pend;   // args: FwdArgs of the launch
+    bool auto_fp32 = false;                // AUTO has seen an overflow: exact kernels first (cleared by pesto_set_precision)
     DevBuf col_seg, col_segend;            // pesto_forward_batch: structure of every atom, end offset of every structure
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     DevBuf in_M, mask_seen;               // pesto_mask_to_segments: host mask staging, one word per residue column
@@ -181,6 +186,8 @@ int check_device_flag(pesto_model* m, hipStream_t st, int* flag_out = nullptr, i
 
 // one launch sequence = F coordinate frames of N atoms / R residues sharing ids, q0 and the residue map (F = 1: the plain
 // collated batch of Model.forward). All pointers are device pointers; X strides are in floats.
+struct FwdArgs;
+int resolve_pending(pesto_model* m);
 struct FwdArgs {
     int64_t N = 0, R = 0, F = 1;
     int k = 0;
@@ -312,19 +319,54 @@ int check_model(const pesto_model* m) { return m ? 0 : fail(PESTO_ERR_INVALID, "
 //               AUTO mode only - F16_SPLIT and FP32 stay asynchronous and unchecked there (bad inputs or an overflow still make
 //               every logit NaN, written by the pool kernel).
 template <typename AfterRun>
-int forward_policy(pesto_model* m, hipStream_t st, const FwdArgs& a, bool sync_check, AfterRun after_run) {
-    const bool exact_first = m->precision == PESTO_PRECISION_FP32 || m->impl != 2;
+int forward_policy(pesto_model* m, hipStream_t st, const FwdArgs& a, bool sync_check, AfterRun after_run, bool defer = false) {
+    const bool exact_first = m->precision == PESTO_PRECISION_FP32 || m->impl != 2 || (m->precision == PESTO_PRECISION_AUTO && m->auto_fp32);
     if (int rc = run_forward(m, st, a, exact_first)) return rc;
     if (int rc = after_run()) return rc;
+    if (defer && m->precision == PESTO_PRECISION_AUTO) {
+        // device pointers: no host synchronisation. The flags word travels to pinned memory behind the launch; the next call on the
+        // handle looks at it (resolve_pending). Until then an overflowed launch has NaN logits (written by the pool kernel).
+        if (!m->pend.ev) HIP_TRY(hipEventCreateWithFlags(&m->pend.ev, hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(m->h_flags + 8, err_ptr(m), sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(m->pend.ev, st));
+        if (!m->pend.args) m->pend.args = new FwdArgs();
+        *static_cast<FwdArgs*>(m->pend.args) = a;
+        m->pend.st = st;
+        m->pend.active = true;
+        return 0;
+    }
     if (!sync_check) return 0;
     int flag = 0;
     const bool may_rerun = m->precision == PESTO_PRECISION_AUTO && !exact_first;
     if (int rc = check_device_flag(m, st, &flag, may_rerun ? 4 : 0)) return rc;
     if ((flag & 4) && may_rerun) {
         m->n_rerun += 1;
+        m->auto_fp32 = true;
         if (int rc = run_forward(m, st, a, true)) return rc;
         if (int rc = after_run()) return rc;
         return check_device_flag(m, st);
+    }
+    return 0;
+}
+
+// the deferred check of the last asynchronous AUTO launch (see forward_policy): called at the start of every entry point of the handle
+int resolve_pending(pesto_model* m) {
+    if (!m->pend.active) return 0;
+    m->pend.active = false;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipEventSynchronize(m->pend.ev));
+    const int flag = m->h_flags[8];
+    if (flag & 1) return fail(PESTO_ERR_INVALID, "the previous (asynchronous) forward had an index of ids_topk outside [0, N]: its logits are NaN");
+    if (flag & 2) return fail(PESTO_ERR_INVALID, "the previous (asynchronous) forward had an index of res_of_atom outside [0, R) (from pesto_mask_to_segments: "
+                                               "a row of M with != 1 member or an empty residue column): its logits are NaN");
+    if (flag & 4) {
+        // repeat it on the exact kernels, on its own stream, into the same z (the caller keeps the buffers of an asynchronous call
+        // valid until the next call on the handle or pesto_synchronize returns)
+        m->n_rerun += 1;
+        m->auto_fp32 = true;
+        Sequence seq(m, m->pend.st);
+        if (seq.rc) return seq.rc;
+        if (int rc = run_forward(m, m->pend.st, *static_cast<FwdArgs*>(m->pend.args), true)) return rc;
     }
     return 0;
 }
@@ -387,6 +429,8 @@ int pesto_destroy(pesto_model* m) {
         b.d_in.release(); b.d_z.release();
     }
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
+    if (m->pend.ev) (void)hipEventDestroy(m->pend.ev);
+    delete static_cast<FwdArgs*>(m->pend.args);
     if (m->ws_ev) (void)hipEventDestroy(m->ws_ev);
     if (m->h_flags) (void)hipHostFree(m->h_flags);
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
@@ -409,20 +453,27 @@ int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* b
 int pesto_synchronize(pesto_model* m) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     HIP_TRY(hipSetDevice(m->device));
+    hipStream_t pst = m->pend.active ? m->pend.st : nullptr;
+    const bool had = m->pend.active;
+    const int rc = resolve_pending(m);          // deferred check of the last asynchronous AUTO launch (may queue its fp32 repeat)
+    if (had) HIP_TRY(hipStreamSynchronize(pst));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    return 0;
+    return rc;
 }
 
 int pesto_set_precision(pesto_model* m, int32_t precision) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     if (precision != PESTO_PRECISION_AUTO && precision != PESTO_PRECISION_F16_SPLIT && precision != PESTO_PRECISION_FP32)
         return fail(PESTO_ERR_INVALID, "precision must be PESTO_PRECISION_AUTO, _F16_SPLIT or _FP32");
+    if (int rc = resolve_pending(m)) return rc;
     m->precision = precision;
+    m->auto_fp32 = false;
     return 0;
 }
 
 int pesto_get_status(const pesto_model* m, int32_t* precision, int64_t* n_forward, int64_t* n_fp32_rerun) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(const_cast<pesto_model*>(m))) return rc;
     if (precision) *precision = m->precision;
     if (n_forward) *n_forward = m->n_forward;
     if (n_fp32_rerun) *n_fp32_rerun = m->n_rerun;
@@ -491,6 +542,7 @@ int forward_common(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_fr
                    int64_t x_atom_stride, const void* ids_topk, int32_t ids_kind, const float* q0, const int32_t* res_of_atom,
                    float* z_out, int32_t frames_per_launch, int32_t ptr_kind, void* stream, int32_t n_struct, const int32_t* struct_offsets) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;
     if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || R > N) return fail(PESTO_ERR_INVALID, "bad sizes N=%lld R=%lld", (long long)N, (long long)R);
     if (n_frames < 1) return fail(PESTO_ERR_INVALID, "n_frames=%lld must be >= 1", (long long)n_frames);
     if (k < 1 || k > KMAX) return fail(PESTO_ERR_INVALID, "k=%d must be in 1..%d", k, KMAX);
@@ -541,7 +593,9 @@ int forward_common(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_fr
             a.F = (c + 1) * n_frames / n_chunks - f0;
             a.X = X + f0 * x_frame_stride;
             a.z_out = z_out + f0 * R * n_out;
-            if (int rc = forward_policy(m, st, a, m->precision == PESTO_PRECISION_AUTO, [] { return 0; })) return rc;
+            // AUTO: asynchronous, checked by the next call (a multi-chunk frame call checks every chunk but the last right here)
+            if (c + 1 < n_chunks) { if (int rc = forward_policy(m, st, a, m->precision == PESTO_PRECISION_AUTO, [] { return 0; })) return rc; }
+            else if (int rc = forward_policy(m, st, a, false, [] { return 0; }, true)) return rc;
         }
         return 0;
     }
@@ -608,6 +662,7 @@ int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, cons
                         const void* const* ids_topk0, int32_t ids_kind, const float* const* q0, const int32_t* const* res_of_atom,
                         float* const* z_out, int32_t batch_mode, void* stream) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;
     if (batch_mode != PESTO_BATCH_COLLATED && batch_mode != PESTO_BATCH_INDEPENDENT)
         return fail(PESTO_ERR_INVALID, "batch_mode must be PESTO_BATCH_COLLATED or PESTO_BATCH_INDEPENDENT");
     if (n_struct < 1 || !N || !R || !k || !X || !ids_topk0 || !q0 || !res_of_atom || !z_out) return fail(PESTO_ERR_INVALID, "bad arguments");
@@ -695,6 +750,7 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
                                int32_t n_index, const int32_t* index_offsets, const int32_t* const* res_of_atom, float* const* z_out,
                                int32_t batch_mode, int32_t* ticket) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;
     if (batch_mode != PESTO_BATCH_COLLATED && batch_mode != PESTO_BATCH_INDEPENDENT)
         return fail(PESTO_ERR_INVALID, "batch_mode must be PESTO_BATCH_COLLATED or PESTO_BATCH_INDEPENDENT");
     if (n_struct < 1 || !N || !R || !k || !X || !ids_topk0 || (!q0 && !q_index) || !res_of_atom || !z_out || !ticket) return fail(PESTO_ERR_INVALID, "bad arguments");
@@ -764,7 +820,7 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
     HIP_TRY(hipMemcpyAsync(b.d_in.p, b.h_in, total, hipMemcpyHostToDevice, m->copy_stream));
     HIP_TRY(hipEventRecord(b.ev_h2d, m->copy_stream));
     HIP_TRY(hipStreamWaitEvent(m->stream, b.ev_h2d, 0));
-    const bool exact = m->precision == PESTO_PRECISION_FP32 || m->impl != 2;
+    const bool exact = m->precision == PESTO_PRECISION_FP32 || m->impl != 2 || (m->precision == PESTO_PRECISION_AUTO && m->auto_fp32);
     if (int rc = queue_slot(m, b, m->stream, exact)) return rc;
     b.busy = true;
     *ticket = m->next_slot;
@@ -787,6 +843,7 @@ int pesto_forward_batch_wait(pesto_model* m, int32_t ticket) {
         if (m->precision != PESTO_PRECISION_AUTO || exact_first)
             return fail(PESTO_ERR_RANGE, "an activation left the f16 range of the split-MFMA path (z is NaN): use PESTO_PRECISION_AUTO or PESTO_PRECISION_FP32");
         m->n_rerun += 1;            // the slot's inputs are still on the device: repeat the launch on the exact fp32 kernels
+        m->auto_fp32 = true;
         if (int rc = queue_slot(m, b, m->stream, true)) return rc;
         HIP_TRY(hipEventSynchronize(b.ev_done));
         flag = b.h_flag[0] | b.h_flag[1];
@@ -884,6 +941,7 @@ int pesto_mask_to_segments(pesto_model* m, int64_t N, int64_t R, const float* M,
 int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, const int32_t* res_of_atom, float* p_out, float* bfactor_out,
                       int32_t ptr_kind, void* stream) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;       // (the usual first consumer of an asynchronous forward's logits)
     if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || !z || (!p_out && !bfactor_out) || (bfactor_out && !res_of_atom)) return fail(PESTO_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(m->device));
     const int n_out = m->cfg.n_out;

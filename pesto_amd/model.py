@@ -37,6 +37,8 @@ class Model:
         self._cc = _lib.make_c_config(self.config, self.precision)
         self._debug = (0, 0)        # pesto_debug_select(layer_kernels, knn_brute_force): test hook
         self._edge_mode = 0         # pesto_debug_edge_mode: test hook
+        self._last_device_call = None           # tensors of the last asynchronous device call (kept alive for its deferred check)
+        self._first_device_call_checked = False
         self._blob = None
         self._handle = None
         self._gpu = 0
@@ -133,6 +135,8 @@ class Model:
         if self._handle is not None:
             _lib.load().pesto_destroy(self._handle)
             self._handle = None
+        self._last_device_call = None
+        self._first_device_call_checked = False
 
     def __del__(self):
         try:
@@ -226,6 +230,14 @@ class Model:
             stream = torch.cuda.current_stream(X.device).cuda_stream
             _lib.check(call(N, k, Xc.data_ptr(), ids.data_ptr(), _lib.IDS_INT64 if ids.dtype == torch.int64 else _lib.IDS_INT32,
                             qc.data_ptr(), roa.data_ptr(), z.data_ptr(), _lib.PTR_DEVICE, stream))
+            # precision "auto" is asynchronous here: the range / input check of this launch is made by the NEXT call on the handle
+            # (or synchronize()), which may repeat it on the fp32 kernels into the same z - its buffers stay referenced until then.
+            # The first device call of a handle is checked at once, so a model whose states leave the f16 range on ordinary inputs
+            # (the reference's trained i_v3_1) switches to the exact kernels before any result is consumed.
+            self._last_device_call = (Xc, ids, qc, roa, z)
+            if not self._first_device_call_checked:
+                self._first_device_call_checked = True
+                self.synchronize()
             return z
         # host path: CPU torch tensors or numpy arrays
         as_torch = _is_torch(X)

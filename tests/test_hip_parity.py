@@ -668,12 +668,22 @@ def test_trained_i_v3_1_range_guard():
     m.set_precision("fp32")
     z_fp32 = m.forward_segments(*args)
     assert np.array_equal(z_fp32, z_auto) and m.status()["n_fp32_rerun"] == 1
-    # device tensors: auto synchronises, checks and repeats as well
+    # after one overflow "auto" runs the exact kernels first (no second repeat) until the precision is set again
+    assert np.array_equal(m.set_precision("auto").forward_segments(*args), z_auto) and m.status()["n_fp32_rerun"] == 2
+    assert np.array_equal(m.forward_segments(*args), z_auto) and m.status()["n_fp32_rerun"] == 2
+    # device tensors: "auto" is asynchronous - the first device call of a model is checked at once (and repeated here), later calls
+    # are checked by the next call on the handle / synchronize(): until then an overflowed launch holds NaN, afterwards the fp32 result
     dev = torch.device("cuda:0")
     m.set_precision("auto").to(dev)
     targs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in args[:4]]
     z_dev = m.forward_segments(*targs, args[4])
-    assert np.array_equal(z_dev.cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 2
+    assert np.array_equal(z_dev.cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 3
+    m.set_precision("auto")                                        # forget the overflow: the next launch runs the split kernels again
+    z_late = m.forward_segments(*targs, args[4])
+    torch.cuda.synchronize()
+    assert torch.isnan(z_late).all()                               # loud until the deferred check has run
+    m.synchronize()
+    assert np.array_equal(z_late.cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 4
     # f16_split: loud failure
     m.set_precision("f16_split")
     with pytest.raises(PestoError) as e:
@@ -684,9 +694,19 @@ def test_trained_i_v3_1_range_guard():
     # the handle is not poisoned: a well-behaved model state afterwards
     m.set_precision("auto")
     assert np.array_equal(m.to("cpu").forward_segments(*args), z_auto)
+    # bad inputs on the asynchronous path are reported by the next call
+    m40d = _model("i_v4_0", "mfma").to(dev)
+    g40 = golden("fwd_i_v4_0_2CUA")
+    t40 = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (g40["X"], g40["ids_topk"].astype(np.int64), onehot(g40["q_idx"], 30), g40["res_of_atom"])]
+    z_ok = m40d.forward_segments(*t40, g40["z"].shape[0])
+    bad_ids = t40[1].clone(); bad_ids[5, 3] = 10 ** 6
+    z_bad = m40d.forward_segments(t40[0], bad_ids, t40[2], t40[3], g40["z"].shape[0])             # returns at once
+    with pytest.raises(PestoError):
+        m40d.synchronize()
+    assert torch.isnan(z_bad).all()
+    assert torch.equal(m40d.forward_segments(*t40, g40["z"].shape[0]), z_ok)
     # and a model that stays in range never pays for the guard
     m40 = _model("i_v4_0", "mfma")
-    g40 = golden("fwd_i_v4_0_2CUA")
     m40.forward_segments(g40["X"], g40["ids_topk"], onehot(g40["q_idx"], 30), g40["res_of_atom"], g40["z"].shape[0])
     assert m40.status() == {"precision": "auto", "n_forward": 1, "n_fp32_rerun": 0}
 
@@ -842,9 +862,10 @@ def test_mask_to_segments_kernel_and_the_reference_signature():
             rows = np.where(roa == r)[0]
             Mb[rows] = 0.0
             Mb[rows, (r + 1) % R] = 1.0
+        z_bad = m(*args, torch.from_numpy(Mb).to(dev))        # asynchronous: NaN logits now, the error at the next call on the handle
         with pytest.raises(PestoError):
-            m(*args, torch.from_numpy(Mb).to(dev))
-            torch.cuda.synchronize()
+            m.synchronize()
+        assert torch.isnan(z_bad).all()
     # host-pointer form reports the bad row itself
     lib = _lib.load()
     Mb = M.copy(); Mb[11] = 0.0
