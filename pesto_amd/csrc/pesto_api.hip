@@ -242,7 +242,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
         return hipEventRecord(m->kev[kevi++], st);
     };
     auto nn_class = [](int nn) { return nn == 8 ? 1 : nn == 16 ? 2 : nn == 32 ? 3 : 4; };
-    if (m->impl == 2 && edge_variant == 0 && m->edge_mode == 4) {
+    if (m->impl == 2 && edge_variant == 0 && m->edge_mode >= 4) {
         // developer mode 4: UNFUSED f16-split layers - per layer one edge launch (Z through memory) and one node launch (finish layer l,
         // records of layer l + 1), state updated in place; measures what the in-kernel finish / prepare phases cost or save
         for (int l = 0; l < m->cfg.n_layers; ++l) {
@@ -251,7 +251,8 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
                         m->rec_nb.as<float>(), m->rec_cen.as<float>(), 0, err_ptr(m));
             HIP_TRY(mark(nn_class(m->cfg.nn[l])));
             launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(),
-                        m->rec_cen.as<float>(), p[0], m->zrec.as<float>(), m->edge_blocks, 0, err_ptr(m));
+                        m->rec_cen.as<float>(), p[0], m->zrec.as<float>(), m->edge_blocks, 0, err_ptr(m), nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, m->edge_mode);
         }
         HIP_TRY(mark(0));
         launch_node(st, m->W, &m->img.layers[m->cfg.n_layers - 1], nullptr, N1, q[0], p[0], m->zrec.as<float>(), m->rec_nb.as<float>(),
@@ -300,7 +301,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     }
     if (m->timing) {
         HIP_TRY(hipEventRecord(m->ev[2], st));
-        m->n_layer_launches = m->impl != 2 ? m->cfg.n_layers : (edge_variant == 0 && m->edge_mode != 4) ? m->cfg.n_layers + 1 : 2 * m->cfg.n_layers + 1;
+        m->n_layer_launches = m->impl != 2 ? m->cfg.n_layers : (edge_variant == 0 && m->edge_mode < 4) ? m->cfg.n_layers + 1 : 2 * m->cfg.n_layers + 1;
         m->have_timing = true;
     }
     launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)NT, (int)RT, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
@@ -490,7 +491,8 @@ int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_
 
 int pesto_debug_edge_mode(pesto_model* m, int32_t mode) {
     if (check_model(m)) return PESTO_ERR_INVALID;
-    if (mode < 0 || mode > 4) return fail(PESTO_ERR_INVALID, "mode must be 0 (per launch), 1 (rendezvous), 2 (node waves), 3 (32-edge tiles) or 4 (unfused 32-edge tiles)");
+    if (mode < 0 || mode > 5)
+        return fail(PESTO_ERR_INVALID, "mode must be 0 (per launch), 1 (rendezvous), 2 (node waves), 3 (32-edge tiles), 4 (unfused, 32-edge tiles) or 5 (unfused, 16-edge tiles)");
     m->edge_mode = mode;
     return 0;
 }

@@ -685,8 +685,13 @@ __device__ __forceinline__ float bperm(int src_byte, float v) {
 #endif
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_byte, __builtin_bit_cast(int, v)));
 }
+// Producer lanes hold the 16-byte pieces of an edge in swizzled order - lane 4 e + s holds piece s ^ (e >= 8 ? 2 : 0) - so that the 32
+// consumer lanes ds_bpermute serves together pull from 32 different banks (lanes l and l + 32 share one; unswizzled, edges e and e + 8
+// collided: 10 of the kernel's 14.8 % SQ_LDS_BANK_CONFLICT, profiles/r03_lds_conflict_ablation.txt). Pure data movement: same bits.
+__device__ __forceinline__ int prod_piece(int lane) { return (lane & 3) ^ ((lane >> 5) << 1); }                    // piece a producer lane loads
+__device__ __forceinline__ int cons_src(int lane) { return (4 * (lane & 15) + ((lane >> 4) ^ (((lane >> 3) & 1) << 1))) << 2; }   // byte address of the lane a consumer pulls
 __device__ __forceinline__ f32x4 to_mfma_lanes(f32x4 v, int lane) {
-    const int src = (4 * (lane & 15) + (lane >> 4)) << 2;
+    const int src = cons_src(lane);
     return f32x4{bperm(src, v[0]), bperm(src, v[1]), bperm(src, v[2]), bperm(src, v[3])};
 }
 // First layer of the four feature blocks fb0 .. fb0+3 of tile t, in three steps so that the caller can software-pipeline:
@@ -702,12 +707,13 @@ template <int NN>
 __device__ __forceinline__ L1Raw l1_issue(int fb0, int t, int lane, const TileCtx& tc, const EdgeWaveScratch& ws,
                                           const float* __restrict__ p_state) {
     L1Raw r;
-    const int rp = 16 * t + (lane >> 2);               // producer lane: edge rp, 16-byte chunk lane & 3
-    const float* pj = p_state + (size_t)ws.nb[rp] * 96 + 8 * (lane & 3);
+    const int rp = 16 * t + (lane >> 2);               // producer lane: edge rp, piece prod_piece(lane) (32 bytes of p_j, 16 of A_j)
+    const int pc = prod_piece(lane);
+    const float* pj = p_state + (size_t)ws.nb[rp] * 96 + 8 * pc;
     r.x0 = ld4(pj); r.x1 = ld4(pj + 4); r.y0 = ld4(pj + 32); r.y1 = ld4(pj + 36); r.z0 = ld4(pj + 64); r.z1 = ld4(pj + 68);
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
-        r.a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * (lane & 3));
+        r.a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * pc);
         r.cA[fb] = tc.cenA[(fb0 + fb) * 64 + lane];
         r.cB[fb] = NN == 8 ? tc.cenB[(fb0 + fb) * 64 + lane] : 0.0f;
     }
@@ -724,13 +730,15 @@ __device__ __forceinline__ L1Head l1_head(const L1Raw& r, int t, int lane, const
     const f32x4 b = r.x1 * rx + r.y1 * ry + r.z1 * rz;
     f16x8 fh, fl;
     split8(a, b, fh, fl);
-    const int src = (4 * (lane & 15) + (lane >> 4)) << 2;
+    const int src = cons_src(lane);
     u32x4 hp = __builtin_bit_cast(u32x4, fh), lp = __builtin_bit_cast(u32x4, fl);
+#ifndef PESTO_ABL_NOBPERM2   // ablation: the p_j . r operands stay in the producer lanes too (results wrong): -8 ds_bpermute per tile and pass
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         hp[j] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)hp[j]);
         lp[j] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)lp[j]);
     }
+#endif
     o.fh = __builtin_bit_cast(f16x8, hp);
     o.fl = __builtin_bit_cast(f16x8, lp);
 #pragma unroll
@@ -2563,7 +2571,7 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
         launch_edge_t<4, true, false>(st, W, lw, N1, io, max_blocks);
     } else if (q_out == nullptr) {
         // unfused f16-split layer (developer mode 4): Z through memory, k_node16 finishes; 32-edge tiles where they exist
-        if (!launch_edge_m32_unfused(st, W, lw, N1, io, 256)) launch_edge_t<12, false, true, true>(st, W, lw, N1, io, 256);
+        if (mode == 5 || !launch_edge_m32_unfused(st, W, lw, N1, io, 256)) launch_edge_t<12, false, true, true>(st, W, lw, N1, io, 256);
     } else {
         // (the finish phase always runs inside the shipped kernel: q_out / p_out are required)
         // fine work items (one centre each for nn >= 16): when they outnumber the 2,048 wave slots of eight-wave workgroups, twelve
