@@ -283,10 +283,21 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        # (the collective libraries announce themselves on stdout - "[Gloo] Rank 0 is connected to ..." - which must carry only the
+        # JSON line: file descriptor 1 points at stderr while the process group comes up)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     config = CONFIGS[args.config]
     n0 = config["em"]["N0"]
@@ -415,6 +426,8 @@ def main():
             "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
             "frac": max(hbm_frac, mfma_frac),
             "traffic": traffic,
+            # SURVEY 8d definition (B): compulsory bytes with a perfect cache - own state read + written (1,024 B) and 4 B of ids per edge
+            "traffic_over_compulsory": (traffic / ((1024.0 + 4.0 * nn_max) * n1)) if traffic else None,
             "avg_launch_ms": dom["avg_launch_ms"], "atoms_per_launch": n1,
             "hbm": {"algorithmic_bytes_per_launch": b_a, "achieved_GBps": b_a / t_s / 1e9, "peak_GBps": PEAK_HBM_GBS, "frac": hbm_frac,
                     "definition": "SURVEY 8d (A): gather-counted bytes, (1,024 + 532 nn) per atom-layer - own state read + written (the "

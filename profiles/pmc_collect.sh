@@ -23,14 +23,17 @@ do
   timeout 240 rocprofv3 --pmc $SET -d $R/gpurun_out/pmc_$TAG/p$i -o pmc --output-format csv -- $CMD > $R/gpurun_out/pmc_$TAG/p$i.log 2>&1 || echo "pass $i failed"
 done
 python - "$R/gpurun_out/pmc_$TAG" "$R" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, re, sys, collections
 root = sys.argv[1]
 sys.path.insert(0, sys.argv[2])
+def key(name):      # kernel key: the whole template argument list of k_edge (the tail of the mangled name would cut it off)
+    m = re.search(r"k_edge<([^>]*)>", name)
+    return "k_edge<" + m.group(1).replace(" ", "") + ">" if m else re.sub(r"\(.*", "", name)[-46:]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][-46:]
+        k = key(row["Kernel_Name"])
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         if row["Counter_Name"] in ("SQ_WAVE_CYCLES", "SQ_INSTS_LDS", "TCC_HIT_sum", "FETCH_SIZE", "WRITE_SIZE"):
             cnt[(k, row["Counter_Name"])] += 1

@@ -777,12 +777,13 @@ def test_stage_layer_forced_edge_mode(layer, mode):
 
 @pytest.mark.parametrize("fixture", ["fwd_i_v4_0_2AYO", "edge_n40", "edge_coincident"])
 def test_forward_golden_forced_edge_modes_agree_bitwise(fixture):
-    """Whole forward in each forced mode against the reference golden; the modes run the same arithmetic in the same order, so they
-    must agree bit for bit with each other and with the per-launch choice."""
+    """Whole forward in each forced mode against the reference golden: 1 rendezvous, 2 node waves (the same arithmetic in the same
+    order: bit-identical), 3 the 32-edge-tile kernel (v_mfma_f32_32x32x16_f16, one pass, online softmax: another summation order),
+    4 / 5 the unfused developer variants (Z through memory, finish / prepare by the node kernel) with 32- / 16-edge tiles."""
     g = golden(fixture)
     roa = g["res_of_atom"]
     zs = []
-    for mode in (1, 2, 3, 4):
+    for mode in (1, 2, 3, 4, 5):
         m = _model("i_v4_0", "mfma").debug_edge_mode(mode)
         z = m.forward_segments(g["X"], g["ids_topk"].astype(np.int64), onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
         assert np.abs(z - g["z"]).max() < 1e-4
