@@ -136,7 +136,11 @@ int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_
  *                           than 64 atoms or coincident atoms;
  *   PESTO_BATCH_INDEPENDENT each structure as in its own call, which is what the reference's bulk inference loops do (one
  *                           structure per forward): max(D) and the wrap target are per structure, so results do not depend on
- *                           how structures were grouped into launches (what sharding over GPUs relies on).
+ *                           how structures were grouped into launches (what sharding over GPUs relies on). Bit for bit under
+ *                           F16_SPLIT / FP32, and under AUTO as long as no launch is repeated on the fp32 kernels: the range guard
+ *                           is one flag per LAUNCH, so a structure that shares a launch with an overflowing batch mate is computed
+ *                           by the exact kernels there and by the split kernels alone (both inside the 1e-4 bound; pesto_get_status
+ *                           tells whether a repeat happened - afterwards the handle runs fp32 first and is independent again).
  * Returns after every z_out[b] is filled. */
 enum { PESTO_BATCH_COLLATED = 0, PESTO_BATCH_INDEPENDENT = 1 };
 int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, const int64_t* R, const int32_t* k,
