@@ -16,11 +16,25 @@ __device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expf(x) - 
 
 // One output column `s` of y = x Wt + b for a group of 32 lanes; x lives in LDS (read as broadcast),
 // Wt[in][out] in global memory (lanes read consecutive floats).
+// The k loop is a chain of dependent FMAs fed by two loads per step; left as a scalar loop every step waited for its own LDS / L2
+// round trip (~90 cycles per k-step: the residue-pool kernel spent 22 us on 576 steps). Eight steps at a time: the inputs as two
+// 16-byte LDS reads, the eight weight loads issued together, the FMAs in the ORIGINAL order (same bits).
 __device__ __forceinline__ float g32_linear(const float* __restrict__ W, const LinearW l, const float* x, int s) {
     if (s >= l.n_out) return 0.0f;
     float acc = l.b >= 0 ? W[l.b + s] : 0.0f;
     const float* w = W + l.w + s;
-    for (int k = 0; k < l.n_in; ++k) acc += x[k] * w[k * l.n_out];
+    const int n_out = l.n_out;
+    int k = 0;
+    if ((reinterpret_cast<size_t>(x) & 15) == 0) {
+        for (; k + 8 <= l.n_in; k += 8) {
+            const float4 xa = *reinterpret_cast<const float4*>(x + k), xb = *reinterpret_cast<const float4*>(x + k + 4);
+            const float w0 = w[(k + 0) * n_out], w1 = w[(k + 1) * n_out], w2 = w[(k + 2) * n_out], w3 = w[(k + 3) * n_out];
+            const float w4 = w[(k + 4) * n_out], w5 = w[(k + 5) * n_out], w6 = w[(k + 6) * n_out], w7 = w[(k + 7) * n_out];
+            acc += xa.x * w0; acc += xa.y * w1; acc += xa.z * w2; acc += xa.w * w3;
+            acc += xb.x * w4; acc += xb.y * w5; acc += xb.z * w6; acc += xb.w * w7;
+        }
+    }
+    for (; k < l.n_in; ++k) acc += x[k] * w[k * n_out];
     return acc;
 }
 
@@ -28,8 +42,8 @@ __device__ __forceinline__ float g32_linear(const float* __restrict__ W, const L
 // q[i+1][:] = em(q0[i][:]) ; 8 atoms per 256-thread block, 32 lanes per atom.  model/model.py:34
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW em, int N, int nq, int n0,
                                                const float* __restrict__ q0, float* __restrict__ q_state, float* __restrict__ p_zero) {
-    __shared__ float xs[8][512];
-    __shared__ float hs[8][64];
+    __shared__ __attribute__((aligned(16))) float xs[8][512];
+    __shared__ __attribute__((aligned(16))) float hs[8][64];
     const int g = threadIdx.x >> 5, s = threadIdx.x & 31;
     const int i = blockIdx.x * 8 + g;
     const int ic = (i < N ? i : N - 1) % nq;   // nq < N: frames of a trajectory share one q0 (row i of every frame)
@@ -436,8 +450,8 @@ __global__ void k_seg_bounds(int N, int R, const int* __restrict__ roa, int* __r
 __global__ __launch_bounds__(256) void k_pool_logits(const float* __restrict__ W, MlpW sam, int N,
                                                      const float* __restrict__ q, const float* __restrict__ p,
                                                      float* __restrict__ a_out) {
-    __shared__ float zin[8][64];
-    __shared__ float hs[8][64];
+    __shared__ __attribute__((aligned(16))) float zin[8][64];
+    __shared__ __attribute__((aligned(16))) float hs[8][64];
     const int g = threadIdx.x >> 5, s = threadIdx.x & 31;
     const int i = blockIdx.x * 8 + g;
     const int ic = i < N ? i : N - 1;
@@ -461,10 +475,10 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
                                                     const int* __restrict__ lo, const int* __restrict__ hi,
                                                     float* __restrict__ qr_out, float* __restrict__ pr_out,
                                                     float* __restrict__ z_out, const int* __restrict__ flags) {
-    __shared__ float qh[128];
-    __shared__ float ph[3][128];
-    __shared__ float hs[64];
-    __shared__ float zr[64];
+    __shared__ __attribute__((aligned(16))) float qh[128];
+    __shared__ __attribute__((aligned(16))) float ph[3][128];
+    __shared__ __attribute__((aligned(16))) float hs[64];
+    __shared__ __attribute__((aligned(16))) float zr[64];
     const int r = blockIdx.x;
     const int lane = threadIdx.x, s = lane & 31, hf = lane >> 5;
     const int i0 = lo[r], i1 = hi[r];

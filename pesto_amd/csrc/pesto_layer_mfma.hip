@@ -524,10 +524,16 @@ __device__ __forceinline__ float dpp_mov(float x) {
 __device__ __forceinline__ float lane_bcast(float x, int src_lane) {   // src_lane must be wave-uniform
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
 }
-// reduce over the 16 lanes of a DPP row (W16) or over each 8-lane half (!W16); every lane ends with the result
+// reduce over the 16 lanes of a DPP row (W16) or over each 8-lane half (!W16); every lane ends with the result.
+// The permuted operand is a bound_ctrl mov_dpp without an `old` value: the compiler folds it into the add (v_add_f32_dpp, one
+// instruction per step instead of v_mov 0 + v_mov_dpp + v_add); the max keeps fmaxf (canonicalisation of the permuted operand + v_max).
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
 template <bool W16, bool IS_MAX>
 __device__ __forceinline__ float row_reduce(float x) {
-#define PESTO_RR(ctrl) { const float y = dpp_mov<ctrl>(x); x = IS_MAX ? fmaxf(x, y) : x + y; }
+#define PESTO_RR(ctrl) { const float y = dpp_perm<ctrl>(x); x = IS_MAX ? fmaxf(x, y) : x + y; }
     PESTO_RR(0xB1)          // quad_perm [1,0,3,2]
     PESTO_RR(0x4E)          // quad_perm [2,3,0,1]
     PESTO_RR(0x141)         // row_half_mirror: i <-> 7-i
@@ -542,9 +548,14 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // =============================================================================================== edge kernel
 #if defined(PESTO_TRACE32)      // developer build: timeline of ONE wave (block 0, wave 0), no per-phase accumulators (they cost registers)
-__device__ unsigned long long g_trace32[4096];
+__device__ unsigned long long g_trace32[4096];     // four timelines of 1024 entries: the last nn = 8 / 16 / 32 / 64 launch
+__device__ int g_trace32_base;                      // (set by the kernel's first mark, id >= 60 + log2(nn / 8))
 __device__ __forceinline__ void trace32(int& n, int id) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n < 4096) g_trace32[n++] = ((unsigned long long)id << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n < 1023) {
+        if (id >= 60 && id < 64) { n = 0; g_trace32_base = (id - 60) * 1024; }
+        g_trace32[g_trace32_base + n++] = ((unsigned long long)id << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull);
+        g_trace32[g_trace32_base + n] = 0;
+    }
 }
 #define PHASE_MARK(k) trace32(tr_n, 30 + (k))
 #define PHASE_INIT() do {} while (0)
@@ -1363,13 +1374,47 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     static_assert(NE == WPB || (FIN && WPB - NE == 4 && NE * A * SUBS == 16), "node waves: four of them, one 16-centre tile per iteration");
     static_assert(!M32 || (HY && NE == WPB && WPB == 8 && NN >= 16 && TI % 2 == 0), "M32: eight-wave workgroups, whole 32-edge tiles");
     __shared__ EdgeSmem<WPB, HY, FIN, NE, M32> sm;
+    int tr_n = 0;           // (developer builds: timeline of one wave)
+    (void)tr_n;
+    TRACE32(NN == 8 ? 60 : NN == 16 ? 61 : NN == 32 ? 62 : 63);
     if (threadIdx.x < 8) sm.xflag[threadIdx.x] = 0;
+    // The edge rows (neighbour id, geometry) of the wave's FIRST work item are requested before the layer constants are staged, so that
+    // their round trip runs under that copy instead of behind the workgroup barrier - a small launch (one structure) is one or two
+    // items per wave deep and pays every such latency in full (one-structure forward: see DESIGN 4.1f).
+    int first_nb = 0;
+    float4 first_geo = float4{0.f, 0.f, 0.f, 0.f};
+    bool first_valid = false, first_item = false;
+    if constexpr (!M32) {
+        const int xcd0 = blockIdx.x & 7, jb0 = blockIdx.x >> 3, nbx0 = gridDim.x >> 3, chunk0 = (n_work + 7) >> 3;
+        const int w_end0 = min(n_work, (xcd0 + 1) * chunk0), it0 = xcd0 * chunk0;
+        const bool tail0 = w_end0 - it0 < nbx0 * NE * SUBS;
+        const int lane0 = threadIdx.x & 63, wave0 = threadIdx.x >> 6;
+        const int work0 = it0 + jb0 * NE * (tail0 ? 1 : SUBS) + wave0;
+        first_item = work0 < w_end0 && (!NODEW || wave0 < NE);
+        if (first_item) {
+            const int i0 = work0 * A + lane0 / NN;
+            const size_t src0 = (size_t)min(i0, N1 - 1) * KMAX + lane0 % NN;
+            first_valid = i0 < N1 && lane0 < 16 * TI;
+            first_nb = ids_s[src0];
+            first_geo = geo[src0];
+        }
+    }
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
         const f32x4* src = reinterpret_cast<const f32x4*>(W + (M32 ? lw.e_lds32 : F16 ? lw.e_lds16 : lw.e_lds));
         f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
         for (int k = threadIdx.x; k < (M32 ? EDGE_LDS_FLOATS_32 : HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS) / 4; k += WPB * 64) dst[k] = src[k];
     }
+    if constexpr (!M32) {
+        if (first_item) {     // rows of the first item -> the wave's scratch (no register survives into the work loop)
+            auto& ws0 = sm.ws[threadIdx.x >> 6];
+            const int l0 = threadIdx.x & 63;
+            ws0.nb[l0] = first_valid ? first_nb : 0;
+            ws0.geo[0][l0] = first_valid ? first_geo.x : 0.f; ws0.geo[1][l0] = first_valid ? first_geo.y : 0.f;
+            ws0.geo[2][l0] = first_valid ? first_geo.z : 0.f; ws0.geo[3][l0] = first_valid ? first_geo.w : 0.f; ws0.geo[4][l0] = 1.0f;
+        }
+    }
     __syncthreads();
+    TRACE32(50);
     const float* w2f = sm.w + EL_W2F;
     const float* w3k = sm.w + EL_W3K;
     const float* w3v = sm.w + EL_W3V;
@@ -1382,8 +1427,6 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     const int chunk = (n_work + 7) >> 3;
     const int w_end = min(n_work, (xcd + 1) * chunk);
     PHASE_DECL();
-    int tr_n = 0;           // (developer builds: timeline of one wave)
-    (void)tr_n;
     float sat = 0.0f;       // range guard of the f16-split path (sat_probe)
     int fin_iter = 0;       // finish phases done (FIN)
     // the trip count is the same for every wave of a workgroup (FIN: workgroup barriers inside); a wave without a work item idles
@@ -1443,7 +1486,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             }
         } else {
         PHASE_INIT();
-        {   // rows of this work item: lane = row
+        if (!(it_start == xcd * chunk && sub == 0)) {   // rows of this work item: lane = row (the first item's rows are staged already)
             const int a = lane / NN, c = lane % NN, i = c0 + a;
             const bool valid = i < N1 && lane < 16 * TI;
             const size_t src = (size_t)min(i, N1 - 1) * KMAX + c;           // unconditional loads, select afterwards
@@ -2405,6 +2448,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     }
     if (F16) sat_flush(sat, flags);
     PHASE_FLUSH();
+    TRACE32(51);
 }
 
 #ifdef PESTO_DEBUG32
@@ -2416,10 +2460,14 @@ extern "C" int pesto_debug_dump32(float* out, int centre) {
 void debug_print_phase_cycles() {
 #ifdef PESTO_TRACE32
     static unsigned long long tr[4096];
-    if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace32), sizeof tr) == hipSuccess && tr[0]) {
-        fprintf(stderr, "[pesto trace32] id:delta_cycles of block 0 wave 0 (last launch that traced):");
-        for (int k = 1; k < 400 && tr[k]; ++k) fprintf(stderr, " %d:%lld", (int)(tr[k] >> 56), (long long)((tr[k] & 0xffffffffffffffull) - (tr[k - 1] & 0xffffffffffffffull)));
-        fprintf(stderr, "\n");
+    if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace32), sizeof tr) == hipSuccess) {
+        for (int b = 0; b < 4; ++b) {
+            const unsigned long long* t = tr + 1024 * b;
+            if (!t[0]) continue;
+            fprintf(stderr, "[pesto trace32] nn %d id:delta_cycles of block 0 wave 0 (last launch):", 8 << b);
+            for (int k = 1; k < 400 && t[k]; ++k) fprintf(stderr, " %d:%lld", (int)(t[k] >> 56), (long long)((t[k] & 0xffffffffffffffull) - (t[k - 1] & 0xffffffffffffffull)));
+            fprintf(stderr, "\n");
+        }
     }
 #endif
 #if defined(PESTO_PROFILE_PHASES) && !defined(PESTO_TRACE32)
