@@ -712,7 +712,7 @@ __device__ __forceinline__ f32x4 to_mfma_lanes(f32x4 v, int lane) {
 //   l1_head  : p_j . r_hat -> f16 hi/lo -> MFMA lane layout, A_j chunks -> MFMA lane layout, centre MFMAs (consumes the raw loads);
 //   l1_tail  : the W1P MFMAs, distance term, ELU.
 struct L1Raw { f32x4 x0, x1, y0, y1, z0, z1, a4[4]; float cA[4], cB[4]; };
-struct L1Head { f16x8 fh, fl; f32x4 a4[4], acc[4]; float d; };
+struct L1Head { f16x8 fh, fl; f32x4 acc[4]; float d; };
 
 template <int NN>
 __device__ __forceinline__ L1Raw l1_issue(int fb0, int t, int lane, const TileCtx& tc, const EdgeWaveScratch& ws,
@@ -754,8 +754,8 @@ __device__ __forceinline__ L1Head l1_head(const L1Raw& r, int t, int lane, const
     o.fl = __builtin_bit_cast(f16x8, lp);
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
-        o.a4[fb] = to_mfma_lanes(r.a4[fb], lane);
-        o.acc[fb] = MFMA(r.cA[fb], tc.bgA, (f32x4{0, 0, 0, 0}));      // sum_c G_i[c] r_c + U_i
+        // A_j + sum_c G_i[c] r_c + U_i: the gathered neighbour term is the accumulator the centre MFMA starts from (no separate add)
+        o.acc[fb] = MFMA(r.cA[fb], tc.bgA, to_mfma_lanes(r.a4[fb], lane));
         if (NN == 8) o.acc[fb] = MFMA(r.cB[fb], tc.bgB, o.acc[fb]);
     }
     o.d = tc.d;
@@ -783,7 +783,7 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
         const f32x4 w4 = ld4(wd + 16 * (fb0 + fb) + 4 * g);
-        h1[fb] = elu4s(o.acc[fb] + o.a4[fb] + o.d * w4);      // every term arrives in the log2 domain
+        h1[fb] = elu4s(o.acc[fb] + o.d * w4);      // every term arrives in the log2 domain
     }
 }
 
@@ -1854,11 +1854,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x4 wq = ld4(&ws.wts[h * 4 + 0][r0]), w1 = ld4(&ws.wts[h * 4 + 1][r0]);
+                const f32x4 wx4 = w1 * gx, wy4 = w1 * gy, wz4 = w1 * gz;      // (vector form: packed multiplies)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     zq[h][0] += wq[r] * v[0][r];
                     zq[h][1] += wq[r] * v[1][r];
-                    const float wx = w1[r] * gx[r], wy = w1[r] * gy[r], wz = w1[r] * gz[r];
+                    const float wx = wx4[r], wy = wy4[r], wz = wz4[r];
                     zp1[h][0][0] += wx * v[2][r]; zp1[h][0][1] += wx * v[3][r];
                     zp1[h][1][0] += wy * v[2][r]; zp1[h][1][1] += wy * v[3][r];
                     zp1[h][2][0] += wz * v[2][r]; zp1[h][2][1] += wz * v[3][r];
