@@ -222,7 +222,7 @@ int oracle_unpack(int64_t N, int k, const float* X, const int32_t* ids, int32_t*
             int64_t j = (int64_t)ids[i * k + c] - 1;
             if (j < 0) j += N;
             float rx = X[3 * j] - X[3 * i], ry = X[3 * j + 1] - X[3 * i + 1], rz = X[3 * j + 2] - X[3 * i + 2];
-            float d = sqrtf(rx * rx + ry * ry + rz * rz);              /* :10 */
+            float d = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));      /* :10 (torch.norm over xyz: an FMA chain in the reference's build) */
             size_t e = (size_t)(i + 1) * k + c;
             ids_s[e] = ids[i * k + c];
             D[e] = d; R[3 * e] = rx; R[3 * e + 1] = ry; R[3 * e + 2] = rz;

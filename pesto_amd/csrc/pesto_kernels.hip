@@ -17,8 +17,22 @@ __device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expf(x) - 
 // One output column `s` of y = x Wt + b for a group of 32 lanes; x lives in LDS (read as broadcast),
 // Wt[in][out] in global memory (lanes read consecutive floats).
 // The k loop is a chain of dependent FMAs fed by two loads per step; left as a scalar loop every step waited for its own LDS / L2
-// round trip (~90 cycles per k-step: the residue-pool kernel spent 22 us on 576 steps). Eight steps at a time: the inputs as two
-// 16-byte LDS reads, the eight weight loads issued together, the FMAs in the ORIGINAL order (same bits).
+// round trip (the residue-pool kernel: 576 steps = 22 us). Steps are taken U at a time: the inputs as 16-byte LDS reads, the U
+// weight loads (L2 hits, ~250 ns a round trip whatever their number) issued together, the FMAs in the ORIGINAL order (same bits).
+template <int U>
+__device__ __forceinline__ float g32_steps(const float* __restrict__ w, int n_out, const float* x, int& k, int n_in, float acc) {
+    for (; k + U <= n_in; k += U) {
+        float wv[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) wv[j] = w[(k + j) * n_out];
+#pragma unroll
+        for (int j = 0; j < U; j += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + k + j);
+            acc += xv.x * wv[j]; acc += xv.y * wv[j + 1]; acc += xv.z * wv[j + 2]; acc += xv.w * wv[j + 3];
+        }
+    }
+    return acc;
+}
 __device__ __forceinline__ float g32_linear(const float* __restrict__ W, const LinearW l, const float* x, int s) {
     if (s >= l.n_out) return 0.0f;
     float acc = l.b >= 0 ? W[l.b + s] : 0.0f;
@@ -26,13 +40,8 @@ __device__ __forceinline__ float g32_linear(const float* __restrict__ W, const L
     const int n_out = l.n_out;
     int k = 0;
     if ((reinterpret_cast<size_t>(x) & 15) == 0) {
-        for (; k + 8 <= l.n_in; k += 8) {
-            const float4 xa = *reinterpret_cast<const float4*>(x + k), xb = *reinterpret_cast<const float4*>(x + k + 4);
-            const float w0 = w[(k + 0) * n_out], w1 = w[(k + 1) * n_out], w2 = w[(k + 2) * n_out], w3 = w[(k + 3) * n_out];
-            const float w4 = w[(k + 4) * n_out], w5 = w[(k + 5) * n_out], w6 = w[(k + 6) * n_out], w7 = w[(k + 7) * n_out];
-            acc += xa.x * w0; acc += xa.y * w1; acc += xa.z * w2; acc += xa.w * w3;
-            acc += xb.x * w4; acc += xb.y * w5; acc += xb.z * w6; acc += xb.w * w7;
-        }
+        acc = g32_steps<32>(w, n_out, x, k, l.n_in, acc);
+        acc = g32_steps<8>(w, n_out, x, k, l.n_in, acc);
     }
     for (; k < l.n_in; ++k) acc += x[k] * w[k * n_out];
     return acc;
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
         const float* xj = Xf + j * xs_atom;
         const float* xi = Xf + (int64_t)i * xs_atom;
         const float rx = xj[0] - xi[0], ry = xj[1] - xi[1], rz = xj[2] - xi[2];
-        const float dd = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float dd = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));      // torch.norm's FMA chain (knn_key)
         ids_s[(size_t)(i + 1) * KMAX + c] = (int)id;
         geo[(size_t)(i + 1) * KMAX + c] = make_float4(rx, ry, rz, dd);
         d = dd;
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
         const float* xj = Xf + j * xs_atom;
         const float* xi = Xf + (int64_t)i * xs_atom;
         const float rx = xj[0] - xi[0], ry = xj[1] - xi[1], rz = xj[2] - xi[2];
-        const float dd = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float dd = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));      // torch.norm's FMA chain (knn_key)
         d = fmaxf(d, dd);
         ids_s[(size_t)(a0 + i + 1) * KMAX + c] = id ? (int)(id + a0) : 0;
         geo[(size_t)(a0 + i + 1) * KMAX + c] = make_float4(rx, ry, rz, dd);
@@ -491,17 +500,27 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
     float mx[4], den[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { mx[c] = -INFINITY; den[c] = 0.0f; }
+#ifdef PESTO_ABL_POOL_NOSWEEP
+    if (0)
+#endif
     for (int i = i0; i < i1; ++i)
         if (roa[i] == r) {
             const float4 v = *reinterpret_cast<const float4*>(a + (size_t)i * 8 + 4 * hf);
             mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z); mx[3] = fmaxf(mx[3], v.w);
         }
+#ifdef PESTO_ABL_POOL_NOSWEEP
+    if (0)
+#endif
     for (int i = i0; i < i1; ++i)
         if (roa[i] == r) {
             const float4 v = *reinterpret_cast<const float4*>(a + (size_t)i * 8 + 4 * hf);
             den[0] += expf(v.x - mx[0]); den[1] += expf(v.y - mx[1]); den[2] += expf(v.z - mx[2]); den[3] += expf(v.w - mx[3]);
         }
     float aq[2] = {0.f, 0.f}, ap[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#ifdef PESTO_ABL_POOL_NOSWEEP
+    aq[0] = q[(size_t)i0 * S + s]; ap[0][0] = p[(size_t)i0 * 96 + s];
+    if (0)
+#endif
     for (int i = i0; i < i1; ++i)
         if (roa[i] == r) {
             const float4 v = *reinterpret_cast<const float4*>(a + (size_t)i * 8 + 4 * hf);
@@ -523,6 +542,10 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
         for (int x = 0; x < 3; ++x) ph[x][s * PH + h] = ap[hh][x];
     }
     __syncthreads();
+#ifdef PESTO_ABL_POOL_NOLINEAR
+    if (hf == 0 && s < n_out) z_out[(size_t)r * n_out + s] = qh[s] + ph[0][s];
+    return;
+#endif
     // zdm on lanes 0..31, zdm_vec on all lanes (lane>>5 picks x = 0/1, then x = 2 by the first half)
     float v = 0.0f;
     if (hf == 0) hs[s] = elu(g32_linear(W, mw.zdm.l[0], qh, s));
@@ -746,7 +769,11 @@ __device__ __forceinline__ unsigned long long knn_merge(unsigned long long top, 
     return m;
 }
 __device__ __forceinline__ unsigned long long knn_key(float rx, float ry, float rz, int local_index) {
-    const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz)));
+    // torch.norm over the contiguous xyz axis is the scalar loop acc = acc + v * v, which the reference's build contracts into an FMA
+    // chain: d = sqrt(fma(z, z, fma(y, y, x * x))) reproduces its distance matrix bit for bit (555,000 pairs of a pdbs_test chain;
+    // separately rounded products agree on 89 % only, and a one-ulp difference reorders two neighbours in about one row of 40,000)
+    // (sqrtf, not __fsqrt_rn: the intrinsic lowers to the bare v_sqrt_f32 - one ulp off in places - while sqrtf is correctly rounded)
+    const float d = sqrtf(__fmaf_rn(rz, rz, __fmaf_rn(ry, ry, __fmul_rn(rx, rx))));
     const unsigned masked = d < 1e-2f ? 1u : 0u;
     return ((unsigned long long)((masked << 31) | __float_as_uint(d)) << 32) | (unsigned)local_index;   // d >= 0: bit 31 is free
 }

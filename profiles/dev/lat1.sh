@@ -2,7 +2,7 @@
 # developer: kernel trace of one-structure forwards (N = 3000): kernel durations vs the gaps between them
 R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp; cd /tmp
 mkdir -p $R/gpurun_out/lat1
-timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/lat1/trace -o trace --output-format csv -- python $R/bench.py --batch 1 --steps 20 --warmup 5 --cpu-budget 0 --no-latency --no-extras --precision f16_split > $R/gpurun_out/lat1/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/lat1/trace -o trace --output-format csv -- python $R/bench.py --batch ${LAT_BATCH:-1} --steps 20 --warmup 5 --cpu-budget 0 --no-latency --no-extras --no-check --precision f16_split > $R/gpurun_out/lat1/log.txt 2>&1
 python - "$R/gpurun_out/lat1" <<'PY'
 import csv, glob, sys, re
 f = glob.glob(sys.argv[1] + "/trace/**/*kernel_trace.csv", recursive=True)[0]

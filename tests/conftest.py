@@ -72,6 +72,28 @@ def cfg4_structure(name):
     return g["X"], g["ids_topk"].astype(np.int32) - 1, onehot(g["q_idx"], 30), M, g["z"]
 
 
+def cfg4_all53(only=None):
+    """Every chain of pdbs_test/ (BASELINE config 4 in full): list of dicts name, X, ids0 (the reference's 0-based ids), ids0_host
+    (pesto_amd.topology.extract_topology), q0, res_of_atom, R, z (reference logits). The fixture holds coordinates, feature /
+    residue indices, the reference logits and a patch list: the topology is recomputed on the host and the generator stored where
+    the reference's ids differ from it - exact fp32 distance ties only, which torch.topk orders arbitrarily."""
+    from pesto_amd.topology import extract_topology
+    g = golden("cfg4_all53")
+    ao, ro, pa = g["atom_offsets"], g["res_offsets"], g["tie_patches"]
+    out = []
+    for i, name in enumerate(g["names"]):
+        if only is not None and name.decode() not in only:
+            continue
+        X = g["X"][ao[i]:ao[i + 1]]
+        host = np.asarray(extract_topology(X, 64)).astype(np.int32)
+        ids0 = host.copy()
+        for _, r, c, v in pa[pa[:, 0] == i]:
+            ids0[r, c] = v
+        out.append(dict(name=name.decode(), X=X, ids0=ids0, ids0_host=host, q0=onehot(g["q_idx"][ao[i]:ao[i + 1]], 30),
+                        res_of_atom=g["res_of_atom"][ao[i]:ao[i + 1]].astype(np.int32), R=int(ro[i + 1] - ro[i]), z=g["z"][ro[i]:ro[i + 1]]))
+    return out
+
+
 @pytest.fixture(scope="session")
 def gpu_available():
     import torch

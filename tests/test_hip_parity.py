@@ -638,6 +638,35 @@ def test_config4_pdbs_test_chains_sharded_and_batched():
     assert np.array_equal(zc, np.concatenate(one_launch, 0))
 
 
+def test_config4_all_53_pdbs_test_chains():
+    """BASELINE config 4 IN FULL: every chain of the reference's pdbs_test/ (53 chains, 1,641 - 3,052 atoms, 135 k atoms) against the
+    reference's one-structure-per-call logits (interfaceome/apply_model.py:57-82), fed the reference's own neighbour ids, through
+    sharding.forward_local - the pipelined bulk path with launches packed to <= 24,576 atoms. The GPU k-NN (pesto_knn_collate) must
+    reproduce the host topology on every chain (which equals the reference's up to the order of exact fp32 distance ties)."""
+    from conftest import cfg4_all53
+    from pesto_amd.sharding import forward_local
+    m = _model("i_v4_1")
+    chains = cfg4_all53()
+    assert len(chains) == 53
+    structs = []
+    for ch in chains:
+        ids_gpu = m.knn_collate(ch["X"], [ch["X"].shape[0]])
+        assert np.array_equal(ids_gpu, ch["ids0_host"].astype(np.int64) + 1), ch["name"]
+        roa = ch["res_of_atom"]
+        M = np.zeros((roa.size, ch["R"]), np.float32)
+        M[np.arange(roa.size), roa] = 1.0
+        structs.append((ch["X"], ch["ids0"], ch["q0"], M))
+    out = forward_local(m, structs, list(range(len(structs))))
+    worst = 0.0
+    for i, ch in enumerate(chains):
+        zh = out[i]
+        assert zh is not None and zh.shape == ch["z"].shape, ch["name"]
+        err = float(np.abs(zh - ch["z"]).max())
+        worst = max(worst, err)
+        assert err < 1e-4, (ch["name"], err)
+    print(f"config 4, 53 chains: max |hip - reference| = {worst:.2e}")
+
+
 def test_config3_i_v3_0_at_n3000():
     """BASELINE config 3 at its stated size (i_v3_0: 16 layers, 123 input features, real weights; synthetic N=3000)."""
     from pesto_amd.topology import mask_to_segments, synthetic_structure

@@ -134,6 +134,20 @@ def test_config4_pdbs_test_chains(name):
     assert z.shape == z_ref.shape and np.abs(z - z_ref).max() < 1e-4
 
 
+def test_config4_chain_with_a_distance_tie():
+    """One chain of the all-53 fixture on the oracle: BH_3BH6_1_B:0, where two neighbours of atom 1481 are at the same fp32 distance and
+    torch.topk ordered them the other way round than the index order of pesto_amd.topology (the patch list restores the reference's
+    ids; slots 51 / 52 are inside every nn = 64 layer's neighbourhood, so the result only differs by summation order)."""
+    from conftest import cfg4_all53
+    (ch,) = cfg4_all53(only=("BH_3BH6_1_B:0",))
+    assert (ch["ids0"] != ch["ids0_host"]).sum() == 2 and sorted(ch["ids0"][1481]) == sorted(ch["ids0_host"][1481])
+    o = _model("i_v4_1")
+    z = o.forward_segments(ch["X"], ch["ids0"] + 1, ch["q0"], ch["res_of_atom"], ch["R"])
+    assert np.abs(z - ch["z"]).max() < 1e-4
+    z_host = o.forward_segments(ch["X"], ch["ids0_host"] + 1, ch["q0"], ch["res_of_atom"], ch["R"])
+    assert np.abs(z_host - ch["z"]).max() < 1e-4
+
+
 def test_config3_i_v3_0_at_n3000():
     """BASELINE config 3 at its stated size: i_v3_0 (16 layers, 123 features, real weights), synthetic N=3000."""
     from pesto_amd.topology import mask_to_segments, synthetic_structure
