@@ -3,7 +3,8 @@
   config 1  i_v4_1 (stacked weights), one real-size chain: N=2,810 R=355 (the 2AYO fixture's inputs)
   config 2  i_v4_1, 8 x synthetic N=3000 (the bench.py workload, repeated here for the percentiles)
   config 3  i_v3_0 (16 layers, N0 = 123, real weights), 8 x synthetic N=3000
-  config 4  i_v4_1, 53 synthetic chains N 1,641-3,052 (the pdbs_test size histogram), batched to <= 24.6k atoms per launch;
+  config 4  i_v4_1, the 53 chains of the reference's pdbs_test/ (N 1,641-3,052; coordinates from the parity fixture), batched to
+            <= 24.6k atoms per launch;
             topology built on the GPU (knn_collate) inside the timed region
   config 5  i_v4_1, one synthetic N=20,000 structure, R=2,500
 usage (GPU box): python profiles/bench_configs.py   -> one JSON line per config"""
@@ -74,8 +75,8 @@ X, ids, q, roa, R3 = make_batch(3000, 8, 1, 123)
 a3 = dev_args(X, ids, q, roa)
 timed(lambda: m30.forward_segments(a3[0], a3[1], a3[2], a3[3], R3), 8, "3: i_v3_0 (16 layers, N0=123), 8 x N=3000")
 
-sizes = [int(n) for n in np.random.default_rng(0).integers(1641, 3053, 53)]
-chains = [synthetic_structure(n, 100 + i, n0=30) for i, n in enumerate(sizes)]
+from bench import config4_structures  # noqa: E402
+chains, sizes, _ = config4_structures(53, m41)        # the 53 REAL pdbs_test chains (tests/golden/cfg4_all53.npz)
 groups = batches(list(range(53)), sizes, 24600)
 prepared = []
 for grp in groups:
@@ -96,7 +97,7 @@ def run4():
         m41.forward_segments(Xd, ids_d, qd, rd, Rg)
 
 
-timed(run4, 53, f"4: i_v4_1, 53 chains N 1641-3052 ({sum(sizes)} atoms) in {len(groups)} launches, GPU k-NN included", warm=2, reps=10)
+timed(run4, 53, f"4: i_v4_1, the 53 pdbs_test chains N 1641-3052 ({sum(sizes)} atoms) in {len(groups)} launches, GPU k-NN included", warm=2, reps=10)
 
 X, ids, q, roa, R5 = make_batch(20000, 1, 1, 30)
 a5 = dev_args(X, ids, q, roa)

@@ -74,7 +74,8 @@ def cfg4_structure(name):
 
 def cfg4_all53(only=None):
     """Every chain of pdbs_test/ (BASELINE config 4 in full): list of dicts name, X, ids0 (the reference's 0-based ids), ids0_host
-    (pesto_amd.topology.extract_topology), q0, res_of_atom, R, z (reference logits). The fixture holds coordinates, feature /
+    (pesto_amd.topology.extract_topology), q0 / q0_all (30 / 123 input features), res_of_atom, R and the reference logits: z (i_v4_1
+    architecture, stacked weights), z_i_v4_0 and z_i_v3_0 (the TRAINED checkpoints). The fixture holds coordinates, feature /
     residue indices, the reference logits and a patch list: the topology is recomputed on the host and the generator stored where
     the reference's ids differ from it - exact fp32 distance ties only, which torch.topk orders arbitrarily."""
     from pesto_amd.topology import extract_topology
@@ -90,7 +91,9 @@ def cfg4_all53(only=None):
         for _, r, c, v in pa[pa[:, 0] == i]:
             ids0[r, c] = v
         out.append(dict(name=name.decode(), X=X, ids0=ids0, ids0_host=host, q0=onehot(g["q_idx"][ao[i]:ao[i + 1]], 30),
-                        res_of_atom=g["res_of_atom"][ao[i]:ao[i + 1]].astype(np.int32), R=int(ro[i + 1] - ro[i]), z=g["z"][ro[i]:ro[i + 1]]))
+                        q0_all=onehot(g["q_idx3"][ao[i]:ao[i + 1]], 123),      # element | residue | atom-name blocks (i_v3_*)
+                        res_of_atom=g["res_of_atom"][ao[i]:ao[i + 1]].astype(np.int32), R=int(ro[i + 1] - ro[i]), z=g["z"][ro[i]:ro[i + 1]],
+                        z_i_v4_0=g["z_i_v4_0"][ro[i]:ro[i + 1]], z_i_v3_0=g["z_i_v3_0"][ro[i]:ro[i + 1]]))
     return out
 
 

@@ -382,12 +382,14 @@ def main_r2():
 
 def main_r3():
     """Round-3 golden: BASELINE config 4 in full - EVERY chain of pdbs_test/ (53 chains, 1,641 - 3,052 atoms) through the i_v4_1
-    architecture (stacked weights), one structure per call like the reference's bulk loop (interfaceome/apply_model.py:57-82).
-    Stored compactly: coordinates, feature index, residue index and the reference logits. The 64-neighbour topology is recomputed by
+    architecture (stacked weights), one structure per call like the reference's bulk loop (interfaceome/apply_model.py:57-82), and
+    the same chains through the TRAINED i_v4_0 and i_v3_0 checkpoints (the latter with all 123 input features).
+    Stored compactly: coordinates, feature indices, residue index and the reference logits. The 64-neighbour topology is recomputed by
     the tests with pesto_amd.topology.extract_topology; the generator compares it with the reference's ids (src/data_encoding.py:
     90-102) for every chain and stores the differences as a patch list. They can only be exact fp32 distance TIES, which torch.topk
     orders arbitrarily (checked here: same distance, same neighbour set per row) - with the patches applied the tests feed the
-    reference's own ids."""
+    reference's own ids. Also checked here for every file: the native reader + preprocessing + encoder (libpesto_io.so) give exactly
+    the coordinates, features and residue map the reference's encode_structure / encode_features give."""
     import glob
     import pickle
     cache = "/tmp/pesto_r3_cache"
@@ -397,19 +399,40 @@ def main_r3():
     m41 = Model41(cfg41).eval()
     from pesto_amd.weights import stack_layers
     from pesto_amd import topology
+    from pesto_amd.structure_io import Structure
     sd41 = stack_layers({k: v.numpy() for k, v in m40.state_dict().items()}, cfg41, residual_scale=0.5)
     print("i_v4_1 stacked", m41.load_state_dict({k: pt.from_numpy(np.array(v)) for k, v in sd41.items()}))
+    cfg30, m30 = load_run("i_v3_0_2021-05-27_14-27")
     import_reference("i_v4_1_2021-09-07_11-21")
-    names, Xs, qs, roas, zs, patches = [], [], [], [], [], []
+    models = (("i_v4_1", m41, False), ("i_v4_0", m40, False), ("i_v3_0", m30, True))
+
+    def cached(name, tag, fn):
+        cf = os.path.join(cache, f"{name}.{tag}.pkl")      # (a reference forward takes up to a minute per chain: its logits are cached in /tmp)
+        if os.path.exists(cf):
+            return pickle.load(open(cf, "rb"))
+        z = fn().astype(np.float32)
+        pickle.dump(z, open(cf, "wb"))
+        return z
+
+    names, Xs, qs, q3s, roas, patches = [], [], [], [], [], []
+    zs = {tag: [] for tag, _, _ in models}
     for f in sorted(glob.glob(os.path.join(REF, "pdbs_test", "*.pdb"))):
         if f.endswith(("_M.pdb", "_T.pdb")):
             continue
         name = os.path.basename(f)[:-4]
-        cf = os.path.join(cache, name + ".pkl")      # (the reference forward takes a minute per chain: its logits are cached in /tmp)
         st = parse_pdb(f)
         X, ids, q, M = encode(st, False)
+        _, _, q_all, _ = encode(st, True)
         Xc, idsc, qc, Mc = collate([[X, ids, q, M]])
+        _, _, qc_all, _ = collate([[X, ids, q_all, M]])
         Xn = Xc.numpy().astype(np.float32)
+        qi, qi3, roa = onehot_to_idx(qc, False).astype(np.uint8), onehot_to_idx(qc_all, True).astype(np.uint8), res_of_atom(Mc).astype(np.int16)
+        # native structure I/O on the same file
+        sn = Structure.read_pdb(f)
+        sn.preprocess()
+        Xio, q0io, roaio, Rio = sn.encode(30)
+        assert np.array_equal(Xio, Xn) and np.array_equal(q0io.argmax(1), qi[:, 0]) and np.array_equal(roaio, roa) and Rio == Mc.shape[1], name
+        assert np.array_equal(sn.encode(123)[1], qc_all.numpy()), name
         mine = np.asarray(topology.extract_topology(Xn, 64)).astype(np.int64)
         ref0 = idsc.numpy().astype(np.int64) - 1
         pch = []
@@ -419,19 +442,17 @@ def main_r3():
             for r, c in diff:
                 assert D[r, mine[r, c]] == D[r, ref0[r, c]] and sorted(mine[r]) == sorted(ref0[r]), (name, r, c)   # a tie, nothing else
                 pch.append((int(r), int(c), int(ref0[r, c])))
-        if os.path.exists(cf):
-            z = pickle.load(open(cf, "rb"))[3]
-        else:
-            z = run_forward(m41, Xc, idsc, qc, Mc).astype(np.float32)
-            pickle.dump((Xn, None, None, z, None), open(cf, "wb"))
-        qi, roa = onehot_to_idx(qc, False).astype(np.uint8), res_of_atom(Mc).astype(np.int16)
-        print(f"  {name}: N={Xn.shape[0]} R={z.shape[0]} |z|max={np.abs(z).max():.2f} tie patches {len(pch)}", flush=True)
+        for tag, mdl, all_f in models:
+            zs[tag].append(cached(name, tag, lambda: run_forward(mdl, Xc, idsc, qc_all if all_f else qc, Mc)))
+        print(f"  {name}: N={Xn.shape[0]} R={Mc.shape[1]} tie patches {len(pch)} |z|max " +
+              " ".join(f"{tag} {np.abs(zs[tag][-1]).max():.2f}" for tag, _, _ in models), flush=True)
         patches += [(len(names), r, c, v) for r, c, v in pch]
-        names.append(name); Xs.append(Xn); qs.append(qi); roas.append(roa); zs.append(z)
+        names.append(name); Xs.append(Xn); qs.append(qi); q3s.append(qi3); roas.append(roa)
     pa = np.array(patches, np.int32).reshape(-1, 4)
     save("cfg4_all53", names=np.array(names).astype("S"), atom_offsets=np.cumsum([0] + [x.shape[0] for x in Xs]).astype(np.int32),
-         res_offsets=np.cumsum([0] + [z.shape[0] for z in zs]).astype(np.int32), X=np.concatenate(Xs, 0), q_idx=np.concatenate(qs, 0),
-         res_of_atom=np.concatenate(roas, 0), z=np.concatenate(zs, 0), tie_patches=pa)
+         res_offsets=np.cumsum([0] + [z.shape[0] for z in zs["i_v4_1"]]).astype(np.int32), X=np.concatenate(Xs, 0), q_idx=np.concatenate(qs, 0),
+         q_idx3=np.concatenate(q3s, 0), res_of_atom=np.concatenate(roas, 0), z=np.concatenate(zs["i_v4_1"], 0),
+         z_i_v4_0=np.concatenate(zs["i_v4_0"], 0), z_i_v3_0=np.concatenate(zs["i_v3_0"], 0), tie_patches=pa)
 
 
 def _pdb_line(rec, serial, name, alt, resname, chain, resnum, icode, xyz, element, occ=1.0, b=20.0):

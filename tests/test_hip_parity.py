@@ -638,33 +638,38 @@ def test_config4_pdbs_test_chains_sharded_and_batched():
     assert np.array_equal(zc, np.concatenate(one_launch, 0))
 
 
-def test_config4_all_53_pdbs_test_chains():
-    """BASELINE config 4 IN FULL: every chain of the reference's pdbs_test/ (53 chains, 1,641 - 3,052 atoms, 135 k atoms) against the
+@pytest.mark.parametrize("tag,zkey,qkey", [("i_v4_1", "z", "q0"), ("i_v4_0", "z_i_v4_0", "q0"), ("i_v3_0", "z_i_v3_0", "q0_all")])
+def test_config4_all_53_pdbs_test_chains(tag, zkey, qkey):
+    """BASELINE config 4 IN FULL: every chain of the reference's pdbs_test/ (53 chains, 1,641 - 3,052 atoms, 132 k atoms) against the
     reference's one-structure-per-call logits (interfaceome/apply_model.py:57-82), fed the reference's own neighbour ids, through
-    sharding.forward_local - the pipelined bulk path with launches packed to <= 24,576 atoms. The GPU k-NN (pesto_knn_collate) must
-    reproduce the host topology on every chain (which equals the reference's up to the order of exact fp32 distance ties)."""
+    sharding.forward_local - the pipelined bulk path with launches packed to <= 24,576 atoms. Three models: the i_v4_1 architecture
+    (32 layers, stacked weights) and the TRAINED i_v4_0 and i_v3_0 (123 input features) checkpoints. The GPU k-NN
+    (pesto_knn_collate) must reproduce the host topology on every chain (which equals the reference's up to the order of exact fp32
+    distance ties)."""
     from conftest import cfg4_all53
     from pesto_amd.sharding import forward_local
-    m = _model("i_v4_1")
+    m = _model(tag)
     chains = cfg4_all53()
     assert len(chains) == 53
     structs = []
     for ch in chains:
-        ids_gpu = m.knn_collate(ch["X"], [ch["X"].shape[0]])
-        assert np.array_equal(ids_gpu, ch["ids0_host"].astype(np.int64) + 1), ch["name"]
+        if tag == "i_v4_1":
+            ids_gpu = m.knn_collate(ch["X"], [ch["X"].shape[0]])
+            assert np.array_equal(ids_gpu, ch["ids0_host"].astype(np.int64) + 1), ch["name"]
         roa = ch["res_of_atom"]
         M = np.zeros((roa.size, ch["R"]), np.float32)
         M[np.arange(roa.size), roa] = 1.0
-        structs.append((ch["X"], ch["ids0"], ch["q0"], M))
+        structs.append((ch["X"], ch["ids0"], ch[qkey], M))
     out = forward_local(m, structs, list(range(len(structs))))
+    assert m.status()["n_fp32_rerun"] == 0      # these models stay inside the f16 range on real chains: no launch repeated in fp32
     worst = 0.0
     for i, ch in enumerate(chains):
         zh = out[i]
-        assert zh is not None and zh.shape == ch["z"].shape, ch["name"]
-        err = float(np.abs(zh - ch["z"]).max())
+        assert zh is not None and zh.shape == ch[zkey].shape, ch["name"]
+        err = float(np.abs(zh - ch[zkey]).max())
         worst = max(worst, err)
         assert err < 1e-4, (ch["name"], err)
-    print(f"config 4, 53 chains: max |hip - reference| = {worst:.2e}")
+    print(f"config 4, 53 chains, {tag}: max |hip - reference| = {worst:.2e}")
 
 
 def test_config3_i_v3_0_at_n3000():
@@ -738,6 +743,40 @@ def test_trained_i_v3_1_range_guard():
     m40 = _model("i_v4_0", "mfma")
     m40.forward_segments(g40["X"], g40["ids_topk"], onehot(g40["q_idx"], 30), g40["res_of_atom"], g40["z"].shape[0])
     assert m40.status() == {"precision": "auto", "n_forward": 1, "n_fp32_rerun": 0}
+
+
+def test_range_guard_on_the_pipelined_bulk_path():
+    """The TRAINED i_v3_1 (states beyond the f16 range) through pesto_forward_batch_submit / _wait with two launches in flight: under
+    "auto" each flagged slot is repeated on the exact fp32 kernels from its own staged inputs when it is waited for (the second slot
+    was queued on the split kernels before the first one was looked at), later submits run the exact kernels first; "f16_split"
+    reports PESTO_ERR_RANGE at the wait. Results = the synchronous "fp32" forward, bit for bit."""
+    from pesto_amd._lib import ERR_RANGE, PestoError
+    g = golden("fwd_i_v3_0_2CUA")
+    roa = g["res_of_atom"]
+    M = np.zeros((roa.size, int(roa.max()) + 1), np.float32)
+    M[np.arange(roa.size), roa] = 1.0
+    st = (g["X"], g["ids_topk"].astype(np.int32) - 1, onehot(g["q_idx"], 123), M)
+    from pesto_amd import Model
+    m = Model(CONFIGS["i_v3_1"])
+    m.load_state_dict(weights("i_v3_1_trained"))
+    z_fp32 = m.set_precision("fp32").forward_batch([st], independent=True)[0]
+    assert np.isfinite(z_fp32).all()
+    m.set_precision("auto")
+    n0 = m.status()["n_fp32_rerun"]
+    t1 = m.forward_batch_submit([st])
+    t2 = m.forward_batch_submit([st, st])
+    z1 = m.forward_batch_wait(t1)
+    z2 = m.forward_batch_wait(t2)
+    assert np.array_equal(z1[0], z_fp32) and np.array_equal(z2[0], z_fp32) and np.array_equal(z2[1], z_fp32)
+    assert m.status()["n_fp32_rerun"] == n0 + 2
+    z3 = m.forward_batch_wait(m.forward_batch_submit([st]))          # the handle runs the exact kernels first now: no repeat
+    assert np.array_equal(z3[0], z_fp32) and m.status()["n_fp32_rerun"] == n0 + 2
+    m.set_precision("f16_split")
+    t = m.forward_batch_submit([st])
+    with pytest.raises(PestoError) as e:
+        m.forward_batch_wait(t)
+    assert e.value.code == ERR_RANGE
+    assert np.array_equal(m.set_precision("auto").forward_batch([st], independent=True)[0], z_fp32)      # the handle still works
 
 
 def test_forward_batch_independent_equals_one_call_per_structure():
