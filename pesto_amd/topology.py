@@ -66,7 +66,9 @@ def _topology_tree(X, knn):
     while True:
         kq = min(n, knn + extra)
         _, idx = tree.query(X64, k=kq)
-        idx = idx.reshape(n, kq)
+        idx = np.sort(idx.reshape(n, kq), axis=1)      # candidates in index order: the stable sorts below then break exact fp32
+                                                       # distance ties by index, like the dense path and k_knn_collate (the tree's
+                                                       # own order is by float64 distance)
         # float32 distances computed the reference's way, then its masking rule
         R = X[idx] - X[:, None, :]
         D = _norm_xyz(R)

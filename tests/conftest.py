@@ -97,6 +97,29 @@ def cfg4_all53(only=None):
     return out
 
 
+def example_complexes(only=None):
+    """Multi-chain complexes of the reference's examples/ (protein + DNA / RNA / lipid / ion / ligand chains, 955 - 15,635 atoms) with
+    the logits of the TRAINED i_v4_0 and i_v3_0 checkpoints: list of dicts like cfg4_all53 (ids0 = the reference's neighbour ids:
+    host topology + the fixture's tie patches)."""
+    from pesto_amd.topology import extract_topology
+    g = golden("examples_complexes")
+    ao, ro, pa = g["atom_offsets"], g["res_offsets"], g["tie_patches"]
+    out = []
+    for i, name in enumerate(g["names"]):
+        if only is not None and name.decode() not in only:
+            continue
+        X = g["X"][ao[i]:ao[i + 1]]
+        host = np.asarray(extract_topology(X, 64)).astype(np.int32)
+        ids0 = host.copy()
+        for _, r, c, v in pa[pa[:, 0] == i]:
+            ids0[r, c] = v
+        q3 = g["q_idx3"][ao[i]:ao[i + 1]]
+        out.append(dict(name=name.decode(), X=X, ids0=ids0, ids0_host=host, q0=onehot(q3[:, :1], 30), q0_all=onehot(q3, 123),
+                        res_of_atom=g["res_of_atom"][ao[i]:ao[i + 1]].astype(np.int32), R=int(ro[i + 1] - ro[i]),
+                        z_i_v4_0=g["z_i_v4_0"][ro[i]:ro[i + 1]], z_i_v3_0=g["z_i_v3_0"][ro[i]:ro[i + 1]]))
+    return out
+
+
 @pytest.fixture(scope="session")
 def gpu_available():
     import torch

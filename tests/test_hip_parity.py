@@ -672,6 +672,31 @@ def test_config4_all_53_pdbs_test_chains(tag, zkey, qkey):
     print(f"config 4, 53 chains, {tag}: max |hip - reference| = {worst:.2e}")
 
 
+@pytest.mark.parametrize("tag,zkey,qkey", [("i_v4_0", "z_i_v4_0", "q0"), ("i_v3_0", "z_i_v3_0", "q0_all")])
+def test_example_complexes_with_nucleic_acids_lipids_ions(tag, zkey, qkey):
+    """Seven multi-chain complexes of the reference's examples/ (DNA / RNA, lipids, ions, ligands next to protein chains; 955 - 15,635
+    atoms, i.e. also beyond the sizes where the host topology uses its k-d tree and the GPU k-NN its cell grid) through the TRAINED
+    i_v4_0 / i_v3_0 checkpoints against the reference's logits (apply_model.ipynb cell 6: read, preprocess, encode, topology,
+    forward). One launch for all of them; the GPU k-NN must reproduce the host topology."""
+    from conftest import example_complexes
+    m = _model(tag)
+    cx = example_complexes()
+    assert len(cx) == 7
+    structs = []
+    for ch in cx:
+        if tag == "i_v4_0":
+            assert np.array_equal(m.knn_collate(ch["X"], [ch["X"].shape[0]]), ch["ids0_host"].astype(np.int64) + 1), ch["name"]
+        roa = ch["res_of_atom"]
+        M = np.zeros((roa.size, ch["R"]), np.float32)
+        M[np.arange(roa.size), roa] = 1.0
+        structs.append((ch["X"], ch["ids0"], ch[qkey], M))
+    out = m.forward_batch(structs, independent=True)
+    assert m.status()["n_fp32_rerun"] == 0
+    for ch, zh in zip(cx, out):
+        assert zh.shape == ch[zkey].shape, ch["name"]
+        assert np.abs(zh - ch[zkey]).max() < 1e-4, (ch["name"], float(np.abs(zh - ch[zkey]).max()))
+
+
 def test_config3_i_v3_0_at_n3000():
     """BASELINE config 3 at its stated size (i_v3_0: 16 layers, 123 input features, real weights; synthetic N=3000)."""
     from pesto_amd.topology import mask_to_segments, synthetic_structure

@@ -148,6 +148,17 @@ def test_config4_chain_with_a_distance_tie():
     assert np.abs(z_host - ch["z"]).max() < 1e-4
 
 
+@pytest.mark.parametrize("tag,zkey,qkey", [("i_v4_0", "z_i_v4_0", "q0"), ("i_v3_0", "z_i_v3_0", "q0_all")])
+def test_example_complex_protein_dna_ion(tag, zkey, qkey):
+    """Two of the examples/ complexes on the oracle: 1ZNS (endonuclease + DNA + ion chains; its row 1441 has the 64th and 65th nearest
+    atoms at the same fp32 distance - the patch list carries the reference's choice) and 1H9D (955 atoms with RNA), trained weights."""
+    from conftest import example_complexes
+    o = _model(tag)
+    for ch in example_complexes(only=("1ZNS", "1H9D")):
+        z = o.forward_segments(ch["X"], ch["ids0"] + 1, ch[qkey], ch["res_of_atom"], ch["R"])
+        assert z.shape == ch[zkey].shape and np.abs(z - ch[zkey]).max() < 1e-4, ch["name"]
+
+
 def test_config3_i_v3_0_at_n3000():
     """BASELINE config 3 at its stated size: i_v3_0 (16 layers, 123 features, real weights), synthetic N=3000."""
     from pesto_amd.topology import mask_to_segments, synthetic_structure
