@@ -43,9 +43,18 @@ typedef enum pesto_status {
  *               ~22-bit mantissa, but the f16 EXPONENT range - activations beyond +-65504 cannot be represented. The kernels
  *               detect that (range guard); the result is then NaN everywhere and, where the call synchronises, PESTO_ERR_RANGE.
  *   FP32      : everything on exact fp32 MFMA (v_mfma_f32_16x16x4_f32), no range limit, about half the speed.
- *   AUTO      : F16_SPLIT, and a forward whose range guard fired is repeated on the FP32 kernels before the call returns
- *               (the reference's trained i_v3_1, model/save/i_v3_1_2021-05-28_12-40, needs this: its states reach 4e5).
- *               Costs one 4-byte read-back + stream synchronisation per call. Default. */
+ *   AUTO      : F16_SPLIT, and a forward whose range guard fired is repeated on the FP32 kernels (the reference's trained i_v3_1,
+ *               model/save/i_v3_1_2021-05-28_12-40, needs this: its states reach 4e5). Default.
+ *               Host-pointer calls (which wait for their D2H copy anyway) repeat before they return. Device-pointer calls stay
+ *               ASYNCHRONOUS: the flags word is copied to pinned memory behind the launch and looked at by the NEXT call on the handle
+ *               (any forward, pesto_postprocess, pesto_get_status, pesto_set_precision, pesto_synchronize): bad inputs are reported
+ *               there (PESTO_ERR_INVALID), a range overflow queues the fp32 repeat of the remembered launch into the same z_out - so
+ *               the caller keeps the buffers of an asynchronous call valid until that next call / pesto_synchronize returns. Until
+ *               then an overflowed launch holds NaN logits (loud, never a plausible wrong number). After one overflow the handle runs
+ *               the FP32 kernels first (no repeat per call) until pesto_set_precision is called again.
+ *               Grouping caveat: the repeat is per LAUNCH, so under AUTO a structure that shares a launch with an overflowing one is
+ *               computed on the fp32 kernels, alone on the split kernels - bitwise independence of the grouping
+ *               (PESTO_BATCH_INDEPENDENT) holds for F16_SPLIT / FP32, and for AUTO while no launch is repeated. */
 typedef enum pesto_precision {
     PESTO_PRECISION_AUTO = 0,
     PESTO_PRECISION_F16_SPLIT = 1,
@@ -88,10 +97,11 @@ int pesto_get_status(const pesto_model* m, int32_t* precision, int64_t* n_forwar
 /* replaces: Model.forward(X, ids_topk, q0, M)  (model/model.py:32-52).
  * ptr_kind: PESTO_PTR_HOST (library stages H2D/D2H itself) or PESTO_PTR_DEVICE (all five buffers on
  * the model's device). stream: a hipStream_t. With device pointers the work is queued on exactly that stream
- * (NULL = HIP's default stream, which is what torch.cuda.current_stream() is by default): under PESTO_PRECISION_AUTO the
- * call then waits for it, checks the flags word (bad ids / residue columns -> PESTO_ERR_INVALID, range overflow -> fp32
- * re-run) and returns; under F16_SPLIT / FP32 it returns at once and nothing is checked (bad inputs or an overflow make
- * every logit NaN). With host pointers NULL selects the model's own stream and the call returns after z has been copied back.
+ * (NULL = HIP's default stream, which is what torch.cuda.current_stream() is by default) and the call returns at once: under
+ * PESTO_PRECISION_AUTO the flags word (bad ids / residue columns, range overflow) is checked by the next call on the handle
+ * (see pesto_precision above); under F16_SPLIT / FP32 nothing is checked (bad inputs or an overflow make every logit NaN).
+ * With host pointers NULL selects the model's own stream, the call returns after z has been copied back, and the checks
+ * (PESTO_ERR_INVALID, the fp32 repeat under AUTO, PESTO_ERR_RANGE under F16_SPLIT) happen before it returns.
  * A handle owns ONE workspace: calls on different streams are ordered after one another through an event, never concurrent.
  * No allocation happens on this path once the grow-only workspace has seen a batch of this size. */
 int pesto_forward(pesto_model* m, int64_t N, int64_t R, int32_t k,
