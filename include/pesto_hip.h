@@ -180,7 +180,8 @@ int pesto_forward_batch_wait(pesto_model* m, int32_t ticket);
 /* bytes of device workspace a batch of (N, R) needs (ownership: SURVEY 8b) */
 int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* bytes);
 
-/* wait for everything queued on the model's own stream */
+/* wait for everything queued on the model's own stream; also runs the deferred check of the last asynchronous AUTO launch (its
+ * error code is returned; an overflowed launch is repeated on the fp32 kernels and waited for) */
 int pesto_synchronize(pesto_model* m);
 
 /* mean duration in milliseconds of the state-update kernels of the most recent pesto_forward, measured with
@@ -194,7 +195,9 @@ int pesto_get_kernel_timing(pesto_model* m, double ms_sum[5], int32_t launches[5
 
 /* replaces: extract_topology (src/data_encoding.py:87-102) + the index half of collate_batch_features (src/dataset.py:100-109)
  * for a concatenated batch: exact k nearest neighbours per atom WITHIN its structure, ascending distance, entries with
- * D < 1e-2 (self, coincident atoms) last, emitted as 1-based batch-global ids zero-padded to 64 columns.
+ * D < 1e-2 (self, coincident atoms) last, emitted as 1-based batch-global ids zero-padded to 64 columns. Distances are rounded
+ * exactly as torch.norm rounds them (sqrt(fma(z, z, fma(y, y, x * x))), correctly rounded sqrt); two atoms at exactly the same float32
+ * distance are ordered by index (the reference's torch.topk leaves that order undefined).
  * X [n_total,3] and ids_out [n_total,64] follow ptr_kind; struct_offsets [n_struct+1] is a HOST array (offsets[0] = 0,
  * offsets[n_struct] = n_total). */
 int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
