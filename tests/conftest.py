@@ -120,6 +120,19 @@ def example_complexes(only=None):
     return out
 
 
+def md_frames(name="1JTG_uL"):
+    """Real MD conformations of one molecule (cluster representatives from the reference's md_analysis/pdbs_clusters/) with the logits of
+    the reference's per-frame loop (frame-0 topology for every frame, trained i_v4_0): X_frames [F,N,3], ids (1-based, the reference's:
+    host topology of frame 0 + tie patches), q0, res_of_atom, R, z [F,R,5]."""
+    from pesto_amd.topology import extract_topology
+    g = golden("frames_md_" + name)
+    ids0 = np.asarray(extract_topology(g["X_frames"][0], 64)).astype(np.int64)
+    for r, c, v in g["tie_patches"]:
+        ids0[r, c] = v
+    return dict(X_frames=g["X_frames"], ids=ids0 + 1, q0=onehot(g["q_idx"], 30), res_of_atom=g["res_of_atom"].astype(np.int32),
+                R=int(g["z"].shape[1]), z=g["z"])
+
+
 @pytest.fixture(scope="session")
 def gpu_available():
     import torch

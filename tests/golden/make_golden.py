@@ -516,6 +516,58 @@ def main_r3_examples():
          tie_patches=np.array(patches, np.int32).reshape(-1, 4))
 
 
+def main_r3_frames(family="1JTG_uL"):
+    """Round-3 golden for the trajectory path on REAL conformations: the MD cluster representatives of one molecule from the reference's
+    md_analysis/pdbs_clusters/ (29 conformations of 1JTG's ligand-side subunit), run as md_analysis/apply_model_md.ipynb cell 6 does -
+    topology, features and residue map of frame 0 for every frame, one forward per frame - with the trained i_v4_0 checkpoint."""
+    import glob
+    import pickle
+    cache = "/tmp/pesto_r3_cache"
+    os.makedirs(cache, exist_ok=True)
+    cfg40, m40 = load_run("i_v4_0_2021-09-07_11-20")
+    sys.path = [REF] + [p for p in sys.path if "/model/save/" not in p and p != REF]
+    for m in [m for m in sys.modules if m == "src" or m.startswith("src.")]:
+        sys.modules.pop(m)
+    from src.structure import (clean_structure, tag_hetatm_chains, split_by_chain, filter_non_atomic_subunits,
+                               remove_duplicate_tagged_subunits, concatenate_chains)
+    from src.data_encoding import encode_structure, encode_features, extract_topology
+    from pesto_amd import topology
+    from pesto_amd.structure_io import Structure
+    files = sorted(glob.glob(os.path.join(REF, "md_analysis", "pdbs_clusters", family + "_*_AUC*.pdb")),
+                   key=lambda f: int(os.path.basename(f).split("_")[2]))
+    frames, first = [], None
+    for f in files:
+        st = Structure.read_pdb(f).to_dict()
+        st["resid"] = st["resid"].astype(np.int32)
+        s = concatenate_chains(remove_duplicate_tagged_subunits(filter_non_atomic_subunits(split_by_chain(tag_hetatm_chains(clean_structure(st))))))
+        if first is None:
+            first = s
+        assert all(np.array_equal(s[k], first[k]) for k in ("name", "element", "resname", "resid", "chain_name")), f     # the same atoms in every file
+        frames.append(s["xyz"].astype(np.float32))
+    X0, M = encode_structure(first)
+    qs = encode_features(first)
+    ids = extract_topology(X0, 64)[0]
+    _, idsc, qc, Mc = collate([[X0, ids, qs[0], M]])
+    Xf = np.stack(frames, 0)
+    mine = np.asarray(topology.extract_topology(Xf[0], 64)).astype(np.int64)
+    ref0 = idsc.numpy().astype(np.int64) - 1
+    pch = []
+    for r, c in np.argwhere(mine != ref0):
+        d = pt.norm(X0 - X0[r], dim=1).numpy()
+        assert d[mine[r, c]] == d[ref0[r, c]], (family, r, c)
+        pch.append((int(r), int(c), int(ref0[r, c])))
+    cf = os.path.join(cache, f"frames_{family}.pkl")
+    if os.path.exists(cf):
+        z = pickle.load(open(cf, "rb"))
+    else:
+        z = np.stack([run_forward(m40, pt.from_numpy(Xf[i]), idsc, qc, Mc) for i in range(Xf.shape[0])], 0).astype(np.float32)
+        pickle.dump(z, open(cf, "wb"))
+    print(f"  {family}: {Xf.shape[0]} frames, N={Xf.shape[1]} R={Mc.shape[1]} tie patches {len(pch)} |z|max {np.abs(z).max():.2f} "
+          f"max frame-to-frame |dz| {np.abs(z[1:] - z[:-1]).max():.2f}")
+    save("frames_md_" + family, X_frames=Xf, q_idx=onehot_to_idx(qc, False).astype(np.uint8), res_of_atom=res_of_atom(Mc).astype(np.int16), z=z,
+         tie_patches=np.array(pch, np.int32).reshape(-1, 3))
+
+
 def _pdb_line(rec, serial, name, alt, resname, chain, resnum, icode, xyz, element, occ=1.0, b=20.0):
     name4 = name if len(name) == 4 else " " + name.ljust(3)
     return "%-6s%5d %4s%1s%3s %1s%4d%1s   %8.3f%8.3f%8.3f%6.2f%6.2f          %2s  " % (
@@ -641,6 +693,8 @@ if __name__ == "__main__":
         main_r3()
     elif "--r3-examples" in sys.argv:
         main_r3_examples()
+    elif "--r3-frames" in sys.argv:
+        main_r3_frames()
     else:
         main()
         main_next()
@@ -648,3 +702,4 @@ if __name__ == "__main__":
         main_r2()
         main_r3()
         main_r3_examples()
+        main_r3_frames()

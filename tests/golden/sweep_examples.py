@@ -6,7 +6,8 @@ multi-model files), and against every *_i0.pdb the reference saved next to them.
     remove_duplicate_tagged_subunits / concatenate_chains / encode_structure / encode_features (src/structure.py,
     src/data_encoding.py) == the native preprocess() + encode(123);
   * native read -> preprocess -> save_pdb == the reference's saved output in every column but the b-factor value.
-Usage: python tests/golden/sweep_examples.py   (prints one line per file; exit code 1 on any difference)"""
+Usage: python tests/golden/sweep_examples.py [glob relative to the reference root]   (one line per file; exit code 1 on any
+difference; default examples/*/*.pdb; "md_analysis/pdbs_clusters/*.pdb" = the 567 MD cluster conformations)"""
 import glob
 import os
 import re
@@ -30,7 +31,8 @@ def main():
                                remove_duplicate_tagged_subunits, concatenate_chains)
     from src.data_encoding import encode_structure, encode_features
     from pesto_amd.structure_io import Structure
-    files = sorted(f for f in glob.glob(os.path.join(mg.REF, "examples", "*", "*.pdb")) if not re.search(r"_i\d\.pdb$", f))
+    pattern = sys.argv[1] if len(sys.argv) > 1 else os.path.join("examples", "*", "*.pdb")      # e.g. "md_analysis/pdbs_clusters/*.pdb"
+    files = sorted(f for f in glob.glob(os.path.join(mg.REF, pattern)) if not re.search(r"_i\d\.pdb$", f))
     bad = 0
     for f in files:
         rel = os.path.relpath(f, mg.REF)

@@ -321,6 +321,20 @@ def test_frames_match_reference_md_loop_golden():
         assert np.array_equal(m.forward_frames_segments(g["X_traj"], g["ids_topk"], q, g["res_of_atom"], R, 1, fpl), singles)
 
 
+def test_frames_on_real_md_conformations():
+    """The trajectory path on REAL conformations: 29 MD cluster representatives of one molecule (the reference's
+    md_analysis/pdbs_clusters/1JTG_uL_*), frame-0 topology for every frame as md_analysis/apply_model_md.ipynb cell 6 does, trained
+    i_v4_0 - against the reference's per-frame loop, and bit-identical to separate single-frame calls."""
+    from conftest import md_frames
+    f = md_frames()
+    m = _model("i_v4_0")
+    z = m.forward_frames_segments(f["X_frames"], f["ids"], f["q0"], f["res_of_atom"], f["R"])
+    assert z.shape == f["z"].shape and z.shape[0] == 29
+    assert np.abs(z - f["z"]).max() < 1e-4, float(np.abs(z - f["z"]).max())
+    singles = np.stack([m.forward_segments(np.ascontiguousarray(f["X_frames"][i]), f["ids"], f["q0"], f["res_of_atom"], f["R"]) for i in (0, 7, 28)])
+    assert np.array_equal(z[[0, 7, 28]], singles)
+
+
 def test_frames_small_structure_per_frame_wrap_and_max():
     """N < 64: padded ids wrap to the last atom OF THE FRAME and max(D) is per frame (per call in the reference)."""
     g = golden("frames_i_v4_0_n40")

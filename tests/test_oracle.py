@@ -124,6 +124,16 @@ def test_oracle_frames_fixed_topology_goldens():
         assert np.abs(z - g["z"][f]).max() < 1e-4
 
 
+def test_oracle_frames_on_real_md_conformations():
+    """Two of the 29 real MD conformations of the frames fixture (frame-0 topology, as the reference's MD loop) on the oracle."""
+    from conftest import md_frames
+    f = md_frames()
+    o = _model("i_v4_0")
+    for i in (3, 28):
+        z = o.forward_segments(np.ascontiguousarray(f["X_frames"][i]), f["ids"], f["q0"], f["res_of_atom"], f["R"])
+        assert np.abs(z - f["z"][i]).max() < 1e-4
+
+
 @pytest.mark.parametrize("name", ["V9_2V9T_1_B_0", "WU_2WUS_1_A_0"])
 def test_config4_pdbs_test_chains(name):
     """BASELINE config 4: chains of pdbs_test/ through the 32-layer i_v4_1 architecture, one structure per call like the reference's
