@@ -57,16 +57,17 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
         loads = [(p, pool.submit(_load, p, n0)) for p in pdb_filepaths]
         writes = []
 
-        def flush(group):
-            if not group:
+        # One launch = pack (host) -> H2D, GPU k-NN, forward (queued, asynchronous) -> collect (post-op, D2H, slice, hand the
+        # b-factor files to the pool). The launch in flight is collected AFTER the next one has been packed, so that the host's
+        # packing runs while the GPU computes (profiles/r03_bulk_breakdown.txt: the loop is GPU-bound, packing was the part of the
+        # host's share that could hide). The post-op is the first consumer of the logits: under precision "auto" it is also where
+        # the deferred range / input check of the forward is made, so it belongs to the collecting half.
+        in_flight = []      # at most one (group, sizes, r_off, z, roa) whose results are still on the device
+
+        def collect():
+            if not in_flight:
                 return
-            sizes = [len(g[1]) for g in group]
-            X = torch.from_numpy(np.concatenate([g[2] for g in group])).to(dev)
-            q = torch.from_numpy(np.concatenate([g[3] for g in group])).to(dev)
-            r_off = np.cumsum([0] + [g[5] for g in group])
-            roa = torch.from_numpy(np.concatenate([g[4] + r_off[i] for i, g in enumerate(group)]).astype(np.int32)).to(dev)
-            ids = model.knn_collate(X, sizes)
-            z = model.forward_segments(X, ids, q, roa, int(r_off[-1]), sizes=sizes)    # one call per structure, semantically
+            group, sizes, r_off, z, roa = in_flight.pop()
             p, bf = model.postprocess(z, roa)
             p, bf = p.cpu().numpy(), bf.cpu().numpy()
             a_off = np.cumsum([0] + sizes)
@@ -76,6 +77,20 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
                     for c in range(bf.shape[0]):
                         out = path[:-4] + suffix.format(c)
                         writes.append(pool.submit(s.save_pdb, out, np.ascontiguousarray(bf[c, a_off[i]:a_off[i + 1]])))
+
+        def flush(group):
+            if not group:
+                return
+            sizes = [len(g[1]) for g in group]
+            Xh = np.concatenate([g[2] for g in group])
+            qh = np.concatenate([g[3] for g in group])
+            r_off = np.cumsum([0] + [g[5] for g in group])
+            rh = np.concatenate([g[4] + r_off[i] for i, g in enumerate(group)]).astype(np.int32)
+            collect()                                                                   # the previous launch (the GPU had the packing time)
+            X, q, roa = torch.from_numpy(Xh).to(dev), torch.from_numpy(qh).to(dev), torch.from_numpy(rh).to(dev)
+            ids = model.knn_collate(X, sizes)
+            z = model.forward_segments(X, ids, q, roa, int(r_off[-1]), sizes=sizes)    # one call per structure, semantically
+            in_flight.append((group, sizes, r_off, z, roa))
 
         group, atoms = [], 0
         for path, fut in loads:
@@ -91,6 +106,7 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
             group.append((path, s, X, q, roa, R))
             atoms += len(s)
         flush(group)
+        collect()
         for w in writes:
             w.result()
     if results_path is not None:
