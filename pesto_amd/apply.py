@@ -57,19 +57,26 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
         loads = [(p, pool.submit(_load, p, n0)) for p in pdb_filepaths]
         writes = []
 
-        # One launch = pack (host) -> H2D, GPU k-NN, forward (queued, asynchronous) -> collect (post-op, D2H, slice, hand the
-        # b-factor files to the pool). The launch in flight is collected AFTER the next one has been packed, so that the host's
-        # packing runs while the GPU computes (profiles/r03_bulk_breakdown.txt: the loop is GPU-bound, packing was the part of the
+        # One launch = pack (host) -> H2D, GPU k-NN, forward (queued, asynchronous) -> fetch (post-op, D2H) -> hand out (slice, b-factor
+        # files to the pool). The launch in flight is fetched AFTER the next one has been packed and handed out after the next one
+        # has been queued, so that the host's packing, slicing and file writing run while the GPU computes (profiles/r03_bulk_breakdown.txt: the loop is GPU-bound, packing was the part of the
         # host's share that could hide). The post-op is the first consumer of the logits: under precision "auto" it is also where
         # the deferred range / input check of the forward is made, so it belongs to the collecting half.
         in_flight = []      # at most one (group, sizes, r_off, z, roa) whose results are still on the device
 
-        def collect():
+        def fetch():
+            """post-op + D2H of the launch in flight -> host arrays (None when nothing is in flight)"""
             if not in_flight:
-                return
+                return None
             group, sizes, r_off, z, roa = in_flight.pop()
             p, bf = model.postprocess(z, roa)
-            p, bf = p.cpu().numpy(), bf.cpu().numpy()
+            return group, sizes, r_off, p.cpu().numpy(), bf.cpu().numpy()
+
+        def hand_out(done):
+            """slice a fetched launch per structure, queue its b-factor files (host only: runs while the GPU computes the next launch)"""
+            if done is None:
+                return
+            group, sizes, r_off, p, bf = done
             a_off = np.cumsum([0] + sizes)
             for i, (path, s, *_rest) in enumerate(group):
                 results[path] = p[r_off[i]:r_off[i + 1]]
@@ -86,11 +93,12 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
             qh = np.concatenate([g[3] for g in group])
             r_off = np.cumsum([0] + [g[5] for g in group])
             rh = np.concatenate([g[4] + r_off[i] for i, g in enumerate(group)]).astype(np.int32)
-            collect()                                                                   # the previous launch (the GPU had the packing time)
+            done = fetch()                                                              # the previous launch (the GPU had the packing time)
             X, q, roa = torch.from_numpy(Xh).to(dev), torch.from_numpy(qh).to(dev), torch.from_numpy(rh).to(dev)
             ids = model.knn_collate(X, sizes)
             z = model.forward_segments(X, ids, q, roa, int(r_off[-1]), sizes=sizes)    # one call per structure, semantically
             in_flight.append((group, sizes, r_off, z, roa))
+            hand_out(done)
 
         group, atoms = [], 0
         for path, fut in loads:
@@ -106,7 +114,7 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
             group.append((path, s, X, q, roa, R))
             atoms += len(s)
         flush(group)
-        collect()
+        hand_out(fetch())
         for w in writes:
             w.result()
     if results_path is not None:
