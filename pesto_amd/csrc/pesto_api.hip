@@ -213,19 +213,28 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     const size_t n_dmax = a.seg_of_atom ? (size_t)a.n_seg : (size_t)a.F;
     float* q[2] = {m->q_a.as<float>(), m->q_b.as<float>()};
     float* p[2] = {m->p_a.as<float>(), m->p_b.as<float>()};
-    if (m->dmax.ensure(n_dmax * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    // per-forward words cleared by ONE memset: [max(D) bit patterns, n_dmax | segment bounds of the pool layer: lo_enc RT, hi RT]
+    const size_t seg_off = (n_dmax + 3) / 4 * 4;      // (in ints)
+    const size_t clear_bytes = ((seg_off + 2 * (size_t)RT) * 4 + 63) / 64 * 64;      // (a multiple of 64 bytes: one fill kernel, no tail launch)
+    if (m->dmax.ensure(clear_bytes)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    int* seg_lo = m->dmax.as<int>() + seg_off;
+    int* seg_hi = seg_lo + RT;
+    const bool bounds_in_embed = a.F == 1;             // found by the unpack launch (trajectory batches expand res_of_atom per frame behind it: separate launches)
     m->n_forward += 1;
     const int* roa = a.roa;
     if (a.F > 1) {
         if (m->roa_f.ensure((size_t)NT * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
         roa = m->roa_f.as<int>();
     }
-    HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
-    HIP_TRY(hipMemsetAsync(m->dmax.p, 0, n_dmax * 4, st));
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[0], st));
-    launch_embed(st, m->W, m->img.model.em, (int)NT, (int)a.N, m->cfg.n0, a.q0, q[0], p[0]);     // also p0 = zeros and the sink rows (model.py:37, model_operations.py:17)
+    // no fill launches: the embed launch (first of the forward) clears the flag words and the per-forward words above; the unpack launch
+    // behind it finds the pool's segment bounds (40 -> 38 launches per forward with the two changes)
+    SegBoundsArgs sb;
+    if (bounds_in_embed) sb = SegBoundsArgs{a.roa, seg_lo, seg_hi, (int)RT, err_ptr(m)};
+    launch_embed(st, m->W, m->img.model.em, (int)NT, (int)a.N, m->cfg.n0, a.q0, q[0], p[0],      // also p0 = zeros and the sink rows (model.py:37, model_operations.py:17)
+                 ClearArgs{m->flags.as<int>(), 2, m->dmax.as<int>(), (int)(clear_bytes / 4)});
     launch_unpack(st, (int)a.N, (int)a.F, a.k, a.X, a.xs_frame, a.xs_atom, a.ids, a.ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(),
-                  dmax_ptr(m), err_ptr(m), a.seg_of_atom, a.seg_end);
+                  dmax_ptr(m), err_ptr(m), a.seg_of_atom, a.seg_end, sb);
     if (a.F > 1) launch_expand_roa(st, (int)a.N, (int)a.R, (int)a.F, a.roa, m->roa_f.as<int>(), err_ptr(m));
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[1], st));
     int cur = 0;
@@ -305,7 +314,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
         m->have_timing = true;
     }
     launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)NT, (int)RT, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
-                m->seg.as<int>(), m->seg.as<int>() + RT, err_ptr(m), nullptr, nullptr, a.z_out);
+                seg_lo, seg_hi, err_ptr(m), nullptr, nullptr, a.z_out, bounds_in_embed);
     HIP_TRY(hipGetLastError());
     return 0;
 }

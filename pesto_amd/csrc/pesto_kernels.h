@@ -8,13 +8,18 @@ namespace pesto {
 
 // N atoms in the batch; q0 has nq rows used with period nq (nq = N, or the frame length of a trajectory batch)
 // p_zero (optional): [N + 1, 96] state array that is zeroed along the way (p0 = zeros), together with the sink row of q_state
-void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero = nullptr);
+// optional extra job of the unpack launch: the residue segment bounds of the pool layer (lo_enc / hi zero-initialised before it)
+struct SegBoundsArgs { const int* roa = nullptr; int* lo_enc = nullptr; int* hi = nullptr; int R = 0; int* err_flag = nullptr; };
+// optional extra job of the embed launch (the first of a forward): clear two arrays of per-forward words (int counts)
+struct ClearArgs { int* p0 = nullptr; int n0 = 0; int* p1 = nullptr; int n1 = 0; };
+void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero = nullptr,
+                  ClearArgs clr = ClearArgs());
 // F coordinate frames of Nf atoms sharing one ids table [Nf,k] (F = 1: a plain collated batch); X strides in floats;
 // dmax_bits[F] must be zeroed. seg_of_atom / seg_end (F = 1 only, may be null): ragged structures that must behave like separate
 // calls - per-structure wrap-around target and max(D); dmax_bits then holds one zeroed word per structure
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
                    int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag, const int* seg_of_atom = nullptr,
-                   const int* seg_end = nullptr);
+                   const int* seg_end = nullptr, SegBoundsArgs sb = SegBoundsArgs());
 void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int* roa_f, int* err_flag);
 void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                      const float* q_in, const float* p_in, float* q_out, float* p_out);
@@ -53,6 +58,7 @@ void launch_mask_to_segments(hipStream_t st, int N, int R, const float* M, int* 
 void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z, const int* roa, float* p_out, float* bf_out, int* err_flag);
 void debug_print_phase_cycles();   // no-op unless built with -DPESTO_PROFILE_PHASES
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,
-                 const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out);
+                 const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out,
+                 bool bounds_ready = false);      // bounds_ready: lo / hi already hold the segment bounds (launch_embed with SegBoundsArgs)
 
 }  // namespace pesto

@@ -47,10 +47,26 @@ __device__ __forceinline__ float g32_linear(const float* __restrict__ W, const L
     return acc;
 }
 
+// segment bounds, zero-initialised (a memset shared with other per-forward words instead of an init kernel): lo_enc[r] = max over the
+// residue's atoms of (0x7fffffff - i), i.e. 0x7fffffff - (min atom index), hi[r] = max + 1; 0 / 0 = no atom (integer atomics: deterministic)
+__device__ __forceinline__ void seg_bound_atom(int i, int R, const int* __restrict__ roa, int* __restrict__ lo_enc, int* __restrict__ hi,
+                                               int* __restrict__ err_flag) {
+    const int r = roa[i];
+    if (r < 0 || r >= R) { atomicOr(err_flag, 2); return; }
+    atomicMax(&lo_enc[r], 0x7fffffff - i);
+    atomicMax(&hi[r], i + 1);
+}
 // ------------------------------------------------------------------------------------------------ embedding
 // q[i+1][:] = em(q0[i][:]) ; 8 atoms per 256-thread block, 32 lanes per atom.  model/model.py:34
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW em, int N, int nq, int n0,
-                                               const float* __restrict__ q0, float* __restrict__ q_state, float* __restrict__ p_zero) {
+                                               const float* __restrict__ q0, float* __restrict__ q_state, float* __restrict__ p_zero,
+                                               ClearArgs clr) {
+    // the forward's per-call words (error flags, max(D) bit patterns, segment bounds of the pool layer) are cleared by workgroup 0
+    // of this FIRST launch instead of by fill launches in front of it: nothing in this kernel reads or writes them otherwise
+    if (blockIdx.x == 0) {
+        for (int k = threadIdx.x; k < clr.n0; k += 256) clr.p0[k] = 0;
+        for (int k = threadIdx.x; k < clr.n1; k += 256) clr.p1[k] = 0;
+    }
     __shared__ __attribute__((aligned(16))) float xs[8][512];
     __shared__ __attribute__((aligned(16))) float hs[8][64];
     const int g = threadIdx.x >> 5, s = threadIdx.x & 31;
@@ -96,7 +112,9 @@ template <typename IdT>
 __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __restrict__ X, int64_t xs_frame, int64_t xs_atom,
                                                  const IdT* __restrict__ ids, int* __restrict__ ids_s, float4* __restrict__ geo,
                                                  unsigned* __restrict__ dmax_bits, int* __restrict__ err_flag,
-                                                 const int* __restrict__ seg_of_atom, const int* __restrict__ seg_end) {
+                                                 const int* __restrict__ seg_of_atom, const int* __restrict__ seg_end, SegBoundsArgs sb) {
+    // (sb: the residue segments of the pool layer, model_operations.py:199-211, only depend on res_of_atom - the thread of an atom's
+    //  first slot finds them here, one launch less at the end of the forward)
     float d = 0.0f;
     const int f = blockIdx.y;
     const float* Xf = X + (int64_t)f * xs_frame;
@@ -105,6 +123,7 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
         const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (e >= (int64_t)Nf * KMAX) return;
         const int i = (int)(e >> 6), c = (int)(e & 63);
+        if (sb.roa && c == 0) seg_bound_atom(i, sb.R, sb.roa, sb.lo_enc, sb.hi, sb.err_flag);
         const int sg = seg_of_atom[i];
         long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
         if (id < 0 || id > Nf) { atomicOr(err_flag, 1); id = 0; }
@@ -127,6 +146,7 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
     // 4 slots per thread (grid-stride by the grid size) keeps the number of blocks, hence atomics, at a quarter
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)Nf * KMAX; e += (int64_t)gridDim.x * 256) {
         const int i = (int)(e >> 6), c = (int)(e & 63);
+        if (sb.roa && c == 0) seg_bound_atom(i, sb.R, sb.roa, sb.lo_enc, sb.hi, sb.err_flag);
         long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
         if (id < 0 || id > Nf) { atomicOr(err_flag, 1); id = 0; }
         long long j = id - 1;
@@ -440,19 +460,10 @@ void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, c
 }
 
 // ------------------------------------------------------------------------------------------------ residue pool
-// segment bounds: lo[r] = min atom index with res_of_atom == r, hi[r] = max + 1 (integer atomics: deterministic)
-__global__ void k_seg_init(int R, int* __restrict__ lo, int* __restrict__ hi) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < R) { lo[r] = 0x7fffffff; hi[r] = 0; }
-}
-__global__ void k_seg_bounds(int N, int R, const int* __restrict__ roa, int* __restrict__ lo, int* __restrict__ hi,
+__global__ void k_seg_bounds(int N, int R, const int* __restrict__ roa, int* __restrict__ lo_enc, int* __restrict__ hi,
                              int* __restrict__ err_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int r = roa[i];
-    if (r < 0 || r >= R) { atomicOr(err_flag, 2); return; }
-    atomicMin(&lo[r], i);
-    atomicMax(&hi[r], i + 1);
+    if (i < N) seg_bound_atom(i, R, roa, lo_enc, hi, err_flag);
 }
 
 // per-atom pool logits a[i][0..7] = sam([q_i | |p_i|]) + F_member   (model_operations.py:199-205)
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
     __shared__ __attribute__((aligned(16))) float zr[64];
     const int r = blockIdx.x;
     const int lane = threadIdx.x, s = lane & 31, hf = lane >> 5;
-    const int i0 = lo[r], i1 = hi[r];
+    const int i0 = 0x7fffffff - lo[r], i1 = hi[r];      // (lo is stored as 0x7fffffff - first member; an empty residue gives i0 > i1)
     // bad ids / residue columns, or an activation beyond the f16 range on the split-MFMA path (flag bit 4): the result would be
     // silently wrong (ELU maps the NaN of an overflowed product to 0), so it is made loud - every logit NaN
     if (i0 >= i1 || (*flags & 7)) {   // (empty residue: the reference degenerates to a whole-batch softmax; NaN here)
@@ -581,21 +592,23 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero) {
-    hipLaunchKernelGGL(k_embed, dim3((N + 7) / 8), dim3(256), 0, st, W, em, N, nq, n0, q0, q_state, p_zero);
+void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero,
+                  ClearArgs clr) {
+    hipLaunchKernelGGL(k_embed, dim3((N + 7) / 8), dim3(256), 0, st, W, em, N, nq, n0, q0, q_state, p_zero, clr);
 }
 
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
-                   int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag, const int* seg_of_atom, const int* seg_end) {
+                   int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag, const int* seg_of_atom, const int* seg_end,
+                   SegBoundsArgs sb) {
     const int64_t n1 = (int64_t)Nf * KMAX, nall = (int64_t)Nf * F * KMAX;
     const dim3 grid1((unsigned)((n1 + (seg_of_atom ? 255 : 1023)) / (seg_of_atom ? 256 : 1024)), (unsigned)F),
         grid2((unsigned)((nall + KMAX + 255) / 256));
     if (ids_kind == PESTO_IDS_INT64)
         hipLaunchKernelGGL(k_unpack1<long long>, grid1, dim3(256), 0, st, Nf, k, X, xs_frame, xs_atom, (const long long*)ids, ids_s, geo,
-                           dmax_bits, err_flag, seg_of_atom, seg_end);
+                           dmax_bits, err_flag, seg_of_atom, seg_end, sb);
     else
         hipLaunchKernelGGL(k_unpack1<int>, grid1, dim3(256), 0, st, Nf, k, X, xs_frame, xs_atom, (const int*)ids, ids_s, geo, dmax_bits,
-                           err_flag, seg_of_atom, seg_end);
+                           err_flag, seg_of_atom, seg_end, sb);
     hipLaunchKernelGGL(k_unpack2, grid2, dim3(256), 0, st, Nf * F, Nf, ids_s, geo, dmax_bits, seg_of_atom);
 }
 
@@ -604,9 +617,12 @@ void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int
 }
 
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,
-                 const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out) {
-    hipLaunchKernelGGL(k_seg_init, dim3((R + 255) / 256), dim3(256), 0, st, R, lo, hi);
-    hipLaunchKernelGGL(k_seg_bounds, dim3((N + 255) / 256), dim3(256), 0, st, N, R, roa, lo, hi, err_flag);
+                 const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out, bool bounds_ready) {
+    if (!bounds_ready) {      // (the forward has them from its embed launch: lo / hi cleared with the other per-forward words)
+        (void)hipMemsetAsync(lo, 0, (size_t)R * sizeof(int), st);
+        (void)hipMemsetAsync(hi, 0, (size_t)R * sizeof(int), st);
+        hipLaunchKernelGGL(k_seg_bounds, dim3((N + 255) / 256), dim3(256), 0, st, N, R, roa, lo, hi, err_flag);
+    }
     hipLaunchKernelGGL(k_pool_logits, dim3((N + 7) / 8), dim3(256), 0, st, W, mw.sam, N, q, p, a_tmp);
     hipLaunchKernelGGL(k_pool_reduce, dim3(R), dim3(64), 0, st, W, mw, n_out, R, q, p, a_tmp, roa, lo, hi, qr_out, pr_out, z_out, err_flag);
 }
