@@ -2,7 +2,6 @@
 """End-to-end bulk throughput of pesto_amd.apply.apply_model: N PDB files on disk -> probabilities (+ 5 b-factor PDB files each),
 i_v4_1, host stages in a thread pool, ~24k atoms per GPU launch. usage (GPU box): python profiles/bench_bulk.py"""
 import gzip, json, os, sys, tempfile, time
-import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import load_weights

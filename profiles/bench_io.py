@@ -1,7 +1,7 @@
 """Timing of the native structure I/O (libpesto_io.so) next to the reference's Python functions on the same arrays.
 BUILD CONTAINER ONLY: imports /root/reference (with a gemmi stub, as tests/golden/make_golden.py does) and reads its examples/.
 Output committed as profiles/r01_io.txt."""
-import sys, time, types, os, tempfile
+import sys, time, types, tempfile
 import numpy as np
 sys.path.insert(0, "/root/repo")
 g = types.ModuleType("gemmi"); g.cif = types.ModuleType("gemmi.cif"); sys.modules["gemmi"] = g; sys.modules["gemmi.cif"] = g.cif

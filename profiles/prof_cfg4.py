@@ -1,6 +1,5 @@
 import sys, time, cProfile, pstats, numpy as np
 sys.path.insert(0, '.')
-import torch
 from bench import config4_structures, load_weights
 from pesto_amd import Model, sharding
 from pesto_amd.config import CONFIGS

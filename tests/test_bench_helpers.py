@@ -3,7 +3,6 @@ captured from the reference's pdbs_test/, launch packing stays within the round 
 import json
 import os
 
-import numpy as np
 
 import bench
 from conftest import ROOT, golden
