@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: ragged batches of random structures (sizes from 2 atoms to a few thousand, including the
 N < 64 / N = 64 / 65 edges, residues of 1 - 30 atoms, non-contiguous residues, k < 64 neighbour tables) through pesto_forward_batch in
-both batch modes and through the pipelined submit / wait path (one-atom structures are left out: alone, such a "structure" has max(D) = 0
+both batch modes and through the pipelined submit / wait path (with its byte-index feature upload) (one-atom structures are left out: alone, such a "structure" has max(D) = 0
 and the reference itself divides 0 by 0, src/model_operations.py:12-20), against the C oracle (per-structure calls for INDEPENDENT, the collated
-call for COLLATED) and bitwise against one-call-per-structure. Trained i_v4_0 weights. usage: python profiles/fuzz_vs_oracle.py [rounds]"""
+call for COLLATED) and bitwise against one-call-per-structure. Trained i_v4_0 weights by default. usage: python profiles/fuzz_vs_oracle.py [rounds] [i_v4_0 | i_v3_0 | i_v4_1]"""
 import os
 import sys
 import time
@@ -20,11 +20,13 @@ from pesto_amd.config import CONFIGS  # noqa: E402
 from pesto_amd.topology import collate_batch_features, extract_topology, mask_to_segments, synthetic_cloud  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+TAG = sys.argv[2] if len(sys.argv) > 2 else "i_v4_0"       # i_v4_0 | i_v3_0 (123 input features) | i_v4_1 (32 layers, stacked weights)
 rng = np.random.default_rng(2024)
-cfg = CONFIGS["i_v4_0"]
+cfg = CONFIGS[TAG]
+N0 = cfg["em"]["N0"]
 m = Model(cfg)
-m.load_state_dict(weights("i_v4_0"))
-o = oracle.OracleModel(cfg, weights("i_v4_0"))
+m.load_state_dict(weights(TAG))
+o = oracle.OracleModel(cfg, weights(TAG))
 # random clouds are harsher than proteins (|z| up to 10, close contacts): the exact-fp32 kernels and the oracle differ by up to 1e-4 on
 # them through fp32 re-association alone, so the sweep looks for shape-dependent BUGS with a 2.5e-4 bound; the 1e-4 parity
 # bound is held on the real structures of tests/golden
@@ -39,8 +41,9 @@ def structure(n, seed):
     if n > 80 and seed % 3 == 0:      # a shorter neighbour table (k < 64 columns)
         k = int(rng.choice([8, 16, 33]))
         ids = np.ascontiguousarray(ids[:, :k])
-    q = np.zeros((n, 30), np.float32)
-    q[np.arange(n), rng.integers(0, 30, n)] = 1.0
+    q = np.zeros((n, N0), np.float32)
+    for lo_, hi_ in ((0, 30),) if N0 == 30 else ((0, 30), (30, 59), (59, 123)):      # one-hot per feature block (element | residue | atom name)
+        q[np.arange(n), rng.integers(lo_, hi_, n)] = 1.0
     # residues: runs of 1 - 30 atoms; sometimes the residue ids are permuted so that columns are not in atom order
     cuts, i = [], 0
     while i < n:
@@ -100,4 +103,4 @@ for it in range(rounds):
     worst = max(worst, e)
     assert e < 10 * TOL, ("collated", it, sizes, e)
     print(f"round {it}: sizes {sizes}  max |hip - oracle| so far {worst:.2e}", flush=True)
-print(f"{rounds} rounds ok in {time.time() - t0:.0f} s, max |hip - oracle| = {worst:.2e}; fp32 re-runs {m.status()['n_fp32_rerun']}")
+print(f"{TAG}: {rounds} rounds ok in {time.time() - t0:.0f} s, max |hip - oracle| = {worst:.2e}; fp32 re-runs {m.status()['n_fp32_rerun']}")
