@@ -14,21 +14,21 @@ from pesto_amd.weights import flatten_state_dict
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libpesto_oracle.so")
-_lib = None
+_SO_WIDE = os.path.join(_HERE, "libpesto_oracle_wide.so")      # same source, double accumulators (header of pesto_oracle.c)
+_libs = {}
 
 
 def build(force=False):
     src = os.path.join(_HERE, "pesto_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) for so in (_SO, _SO_WIDE)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"] if force else ["make", "-C", _HERE, "-s"])
     return _SO
 
 
-def _load():
-    global _lib
-    if _lib is None:
+def _load(wide=False):
+    if wide not in _libs:
         build()
-        lib = ctypes.CDLL(_SO)
+        lib = ctypes.CDLL(_SO_WIDE if wide else _SO)
         c_p, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
         P = ctypes.POINTER
         lib.oracle_blob_size.argtypes = [P(PestoConfig), P(i64)]
@@ -42,8 +42,8 @@ def _load():
         lib.oracle_layer.argtypes = [c_p, ctypes.c_int, i64, ctypes.c_int, c_p, c_p, c_p, c_p, c_p]
         lib.oracle_pool.argtypes = [c_p, i64, i64, c_p, c_p, c_p, c_p, c_p, c_p]
         lib.oracle_forward.argtypes = [c_p, i64, i64, ctypes.c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int]
-        _lib = lib
-    return _lib
+        _libs[wide] = lib
+    return _libs[wide]
 
 
 def _f32(a):
@@ -60,7 +60,8 @@ def _ptr(a):
 
 def set_threads(n):
     """OpenMP team size of the following oracle calls (n < 1: all cores)."""
-    _load().oracle_set_threads(int(n))
+    for lib in list(_libs.values()) or [_load()]:
+        lib.oracle_set_threads(int(n))
 
 
 def blob_size(config):
@@ -71,29 +72,31 @@ def blob_size(config):
 
 
 class OracleModel:
-    """CPU oracle with the reference Module's call shape: OracleModel(config, state_dict)(X, ids_topk, q0, M)."""
+    """CPU oracle with the reference Module's call shape: OracleModel(config, state_dict)(X, ids_topk, q0, M).
+    wide=True: the build with double accumulators (float32 storage) - the checker for ill-conditioned inputs."""
 
-    def __init__(self, config, state_dict):
+    def __init__(self, config, state_dict, wide=False):
         self.config = config
         self.cc = make_c_config(config)
+        self._l = _load(bool(wide))
         blob = _f32(flatten_state_dict(config, state_dict))
         h = ctypes.c_void_p()
-        rc = _load().oracle_create(ctypes.byref(self.cc), _ptr(blob), blob.size, ctypes.byref(h))
+        rc = self._l.oracle_create(ctypes.byref(self.cc), _ptr(blob), blob.size, ctypes.byref(h))
         if rc != 0:
             raise RuntimeError(f"oracle_create failed: {rc}")
         self.h = h
         self.n_out = self.cc.n_out
 
     def __del__(self):
-        if getattr(self, "h", None):
-            _load().oracle_destroy(self.h)
+        if getattr(self, "h", None) and getattr(self, "_l", None) is not None:
+            self._l.oracle_destroy(self.h)
             self.h = None
 
     # ---- stages
     def embed(self, q0):
         q0 = _f32(q0)
         out = np.empty((q0.shape[0], 32), np.float32)
-        _load().oracle_embed(self.h, q0.shape[0], _ptr(q0), _ptr(out))
+        self._l.oracle_embed(self.h, q0.shape[0], _ptr(q0), _ptr(out))
         return out
 
     @staticmethod
@@ -109,7 +112,7 @@ class OracleModel:
     def layer(self, layer, ids_s, D, R, q, p):
         q, p = _f32(q).copy(), _f32(p).copy()
         ids_s, D, R = _i32(ids_s), _f32(D), _f32(R)
-        rc = _load().oracle_layer(self.h, layer, q.shape[0], ids_s.shape[1], _ptr(ids_s), _ptr(D), _ptr(R), _ptr(q), _ptr(p))
+        rc = self._l.oracle_layer(self.h, layer, q.shape[0], ids_s.shape[1], _ptr(ids_s), _ptr(D), _ptr(R), _ptr(q), _ptr(p))
         assert rc == 0
         return q, p
 
@@ -118,7 +121,7 @@ class OracleModel:
         qr = np.empty((R, 32), np.float32)
         pr = np.empty((R, 3, 32), np.float32)
         z = np.empty((R, self.n_out), np.float32)
-        rc = _load().oracle_pool(self.h, q.shape[0], R, _ptr(q), _ptr(p), _ptr(roa), _ptr(qr), _ptr(pr), _ptr(z))
+        rc = self._l.oracle_pool(self.h, q.shape[0], R, _ptr(q), _ptr(p), _ptr(roa), _ptr(qr), _ptr(pr), _ptr(z))
         if rc != 0:
             raise RuntimeError("oracle_pool: empty residue")
         return qr, pr, z
@@ -130,7 +133,7 @@ class OracleModel:
         z = np.empty((R, self.n_out), np.float32)
         qs = np.empty((n + 1, 32), np.float32) if return_state else None
         ps = np.empty((n + 1, 3, 32), np.float32) if return_state else None
-        rc = _load().oracle_forward(self.h, n, R, k, _ptr(X), _ptr(ids), _ptr(q0), _ptr(roa), _ptr(z),
+        rc = self._l.oracle_forward(self.h, n, R, k, _ptr(X), _ptr(ids), _ptr(q0), _ptr(roa), _ptr(z),
                                     _ptr(qs), _ptr(ps), stop_after)
         if rc != 0:
             raise RuntimeError(f"oracle_forward failed: {rc}")

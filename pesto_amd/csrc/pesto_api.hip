@@ -280,8 +280,14 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
         launch_node(st, m->W, nullptr, &m->img.layers[0], N1, q[0], p[0], m->zrec.as<float>(), rnb[0], rcen, edge_variant, err_ptr(m));
         for (int l = 0; l < L; ++l) {
             HIP_TRY(mark(nn_class(m->cfg.nn[l])));
+#ifdef PESTO_ABL_NOPREP      // timing-only ablation: no prepare phase (every layer reads the first layer's records)
+            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), rnb[0], rcen, p[cur], nullptr, m->edge_blocks,
+                        edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1], nullptr, rnb[1], rcen,
+#else
             launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), rnb[cur], rcen, p[cur], nullptr, m->edge_blocks,
-                        edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1], l + 1 < L ? &m->img.layers[l + 1] : nullptr, rnb[cur ^ 1], rcen,
+                        edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1],
+                        l + 1 < L ? &m->img.layers[l + 1] : nullptr, rnb[cur ^ 1], rcen,
+#endif
                         m->edge_mode);
             cur ^= 1;
         }

@@ -546,6 +546,24 @@ __device__ __forceinline__ float row_reduce(float x) {
 // (vmcnt(0)), which would expose the latency of the loads the finish phase deliberately issues ahead of the rendezvous
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// timing-only ablations of the memory side (results wrong; profiles/ab.sh): PESTO_ABL_NOGATHER = every neighbour gather (A_j, p_j) reads one
+// of 8 hot rows; PESTO_ABL_NOCENLD = every centre-record / own-state read hits one of 16 hot records; PESTO_ABL_NOPREPST = the prepare
+// phase's record stores alias into 16 records (the stores are issued, the fabric sees 40 KB)
+#ifdef PESTO_ABL_NOGATHER
+#define ABL_NB(x) ((x) & 7)
+#else
+#define ABL_NB(x) (x)
+#endif
+#ifdef PESTO_ABL_NOCENLD
+#define ABL_CEN(x) ((x) & 15)
+#else
+#define ABL_CEN(x) (x)
+#endif
+#ifdef PESTO_ABL_NOPREPST
+#define ABL_ST(x) ((x) & 15)
+#else
+#define ABL_ST(x) (x)
+#endif
 // =============================================================================================== edge kernel
 #if defined(PESTO_TRACE32)      // developer build: timeline of ONE wave (block 0, wave 0), no per-phase accumulators (they cost registers)
 __device__ unsigned long long g_trace32[4096];     // four timelines of 1024 entries: the last nn = 8 / 16 / 32 / 64 launch
@@ -669,18 +687,14 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
     TileCtx c;
     const int row = 16 * t + e;
     const int aA = NN == 8 ? 2 * t : (16 * t) / NN;
-    c.cenA = rec_cen + (size_t)min(c0 + aA, N1 - 1) * REC_CEN;
-    c.cenB = rec_cen + (size_t)min(c0 + aA + 1, N1 - 1) * REC_CEN;
+    c.cenA = rec_cen + (size_t)ABL_CEN(min(c0 + aA, N1 - 1)) * REC_CEN;
+    c.cenB = rec_cen + (size_t)ABL_CEN(min(c0 + aA + 1, N1 - 1)) * REC_CEN;
     c.rx = ws.geo[0][row]; c.ry = ws.geo[1][row]; c.rz = ws.geo[2][row]; c.d = ws.geo[3][row];
     const float bg = ws.geo[g == 3 ? 4 : g][row];      // B operand of the centre MFMA: (r_x, r_y, r_z, 1)[k = g], one LDS read
     c.bgA = (NN == 8 && e >= 8) ? 0.0f : bg;
     c.bgB = (NN == 8 && e >= 8) ? bg : 0.0f;
-#ifdef PESTO_ABL_NOGATHER
-    c.recj = rec_nb + (size_t)(row & 7) * REC_NB;      // ablation: every edge reads one of 8 hot records
-#else
-    c.recj = rec_nb + (size_t)ws.nb[row] * (HY ? REC_A : REC_NB);
-#endif
-    c.recj_p = rec_nb + (size_t)ws.nb[16 * t + ((16 * g + e) >> 2)] * (HY ? REC_A : REC_NB);
+    c.recj = rec_nb + (size_t)ABL_NB(ws.nb[row]) * (HY ? REC_A : REC_NB);
+    c.recj_p = rec_nb + (size_t)ABL_NB(ws.nb[16 * t + ((16 * g + e) >> 2)]) * (HY ? REC_A : REC_NB);
     return c;
 }
 
@@ -720,7 +734,7 @@ __device__ __forceinline__ L1Raw l1_issue(int fb0, int t, int lane, const TileCt
     L1Raw r;
     const int rp = 16 * t + (lane >> 2);               // producer lane: edge rp, piece prod_piece(lane) (32 bytes of p_j, 16 of A_j)
     const int pc = prod_piece(lane);
-    const float* pj = p_state + (size_t)ws.nb[rp] * 96 + 8 * pc;
+    const float* pj = p_state + (size_t)ABL_NB(ws.nb[rp]) * 96 + 8 * pc;
     r.x0 = ld4(pj); r.x1 = ld4(pj + 4); r.y0 = ld4(pj + 32); r.y1 = ld4(pj + 36); r.z0 = ld4(pj + 64); r.z1 = ld4(pj + 68);
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
@@ -1571,7 +1585,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 }
                 // lane (e, g): kacc[0..2] = key of part g for edge row; logits against Q[0] (scalar) or Q[1] (vector)
                 const int aMine = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
-                const float* Qv = rec_cen + (size_t)min(c0 + aMine, N1 - 1) * REC_CEN + 512 + (g == 0 ? 0 : 6);
+                const float* Qv = rec_cen + (size_t)ABL_CEN(min(c0 + aMine, N1 - 1)) * REC_CEN + 512 + (g == 0 ? 0 : 6);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
                     ws.wts[h * 4 + g][16 * t + e] = (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) * inv_sdk;
@@ -1705,7 +1719,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             if (t % TPC == 0) {
 #pragma unroll
                 for (int sel = 0; sel < (NN == 8 ? 2 : 1); ++sel) {
-                    const int ic = min(c0 + (NN == 8 ? 2 * t + sel : (16 * t) / NN), N1 - 1);
+                    const int ic = ABL_CEN(min(c0 + (NN == 8 ? 2 * t + sel : (16 * t) / NN), N1 - 1));
                     pi_pre[sel][0] = p_state[(size_t)ic * 96 + lane];
                     pi_pre[sel][1] = p_state[(size_t)ic * 96 + 64 + (lane & 31)];
                 }
@@ -1719,7 +1733,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             {
                 int nbj[4];
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ws.nb[16 * t + 2 * i2 + (esub & 1)];
+                for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 2 * i2 + (esub & 1)]);
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
             }
@@ -1786,7 +1800,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             {   // second half of the tile's edges: these loads land during the MFMA phase
                 int nbj[4];
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)];
+                for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)]);
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
             }
@@ -2047,7 +2061,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     split8(a0, a1, zh[kgp], zl[kgp]);
                 }
             };
-            float* cen = rec_cen_out + (size_t)ci * REC_CEN;
+            float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
             f32x4 st[2], h[2];
             if (role == 0) {   // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147, :151)
                 f16x8 w0[2][4], w1[4], w2[4];            // [kgp][(m, hi|lo)], [(m, hi|lo)]
@@ -2220,8 +2234,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     }
                     sat_probe(sat, a[0][0]);
                     if (valid) {
-                        float* cen = rec_cen_out + (size_t)ci * REC_CEN;
-                        float* nb = rec_nb_out + (size_t)ci * REC_A;
+                        float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
+                        float* nb = rec_nb_out + (size_t)ABL_ST(ci) * REC_A;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
@@ -2263,7 +2277,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             const float* zr = sm.zrows[cw][gen][cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
             const float* fb = W + lw.h_q0 + lane * 4;       // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
             float* xs = sm.xch + gen * 2048;                // [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column 16][4]
-            float* cen = rec_cen_out + (size_t)ci * REC_CEN;
+            float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
             f16x8 zh[2], zl[2];
             auto rows = [&]() {                 // wait for the eight edge waves, then this role's part of the 16 rows as hi/lo B operands
                 lds_wait_ge<16>(&sm.xflag[XF_READY + gen], NE * ((fin_iter >> 1) + 1));
@@ -2407,7 +2421,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     }
                     sat_probe(sat, a[0][0]);
                     if (valid) {
-                        float* nb = rec_nb_out + (size_t)ci * REC_A;
+                        float* nb = rec_nb_out + (size_t)ABL_ST(ci) * REC_A;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);

@@ -26,10 +26,11 @@ cfg = CONFIGS[TAG]
 N0 = cfg["em"]["N0"]
 m = Model(cfg)
 m.load_state_dict(weights(TAG))
-o = oracle.OracleModel(cfg, weights(TAG))
-# random clouds are harsher than proteins (|z| up to 10, close contacts): the exact-fp32 kernels and the oracle differ by up to 1e-4 on
-# them through fp32 re-association alone, so the sweep looks for shape-dependent BUGS with a 2.5e-4 bound; the 1e-4 parity
-# bound is held on the real structures of tests/golden
+o = oracle.OracleModel(cfg, weights(TAG), wide=True)      # double accumulators, float32 storage: within 5e-5 of the fp64 reference where the
+# float32-accumulating port is 7e-4 off (tests/test_fuzz_pins.py)
+# random clouds are harsher than proteins (|z| up to 15, 2-atom members, states |p| ~ 50): the REFERENCE's own fp32 run is up to 1.2e-4
+# from its fp64 run on them (tests/golden/make_fuzz_pins.py), so the sweep asserts 2.5e-4 against the wide oracle (no factor on top);
+# the pinned cases and the seeded leg with the reference's own logits are tests/test_fuzz_pins.py
 TOL = 2.5e-4
 SIZES = [2, 3, 17, 40, 63, 64, 65, 66, 100, 129, 500, 1023, 1024, 1025, 2000, 3100]
 
@@ -75,13 +76,13 @@ for it in range(rounds):
         single = m.forward_batch([st], independent=True)[0]
         e = float(np.abs(z_ind[j] - z_ref).max())
         worst = max(worst, e)
-        if not e < TOL:
+        if not e < 1e-4:
             m.set_precision("fp32")
             z32 = m.forward_batch([st], independent=True)[0]
             m.set_precision("auto")
             print(f"   independent round {it} structure {j} ({sizes[j]} atoms, k = {st[1].shape[1]}): max err {e:.2e}, |z|max {np.abs(z_ref).max():.1f}; "
                   f"exact-fp32 kernels vs oracle {np.abs(z32 - z_ref).max():.2e}", flush=True)
-        assert e < 10 * TOL, ("independent", it, j, sizes[j], e)
+        assert e < TOL, ("independent", it, j, sizes[j], e)
         assert np.array_equal(z_ind[j], single) and np.array_equal(z_pipe[j], single), ("bitwise", it, j, sizes[j])
     # COLLATED: the reference's forward on the collated batch (wrap target = last atom of the batch, one max(D))
     Xc, idc, qc, Mc = collate_batch_features([list(s) for s in structs])
@@ -89,7 +90,7 @@ for it in range(rounds):
     z_col = np.concatenate(m.forward_batch(structs, independent=False), 0)
     z_ref = o.forward_segments(Xc, idc, qc, roa_c, R_c)
     e = float(np.abs(z_col - z_ref).max())
-    if not e < TOL:      # where, and is it the split arithmetic or fp32 re-association? (the exact-fp32 kernels on the same batch)
+    if not e < 1e-4:      # where, and is it the split arithmetic or fp32 re-association? (the exact-fp32 kernels on the same batch)
         err = np.abs(z_col - z_ref)
         r = int(err.max(1).argmax())
         offs = np.cumsum([0] + [s_[3].shape[1] for s_ in structs])
@@ -101,6 +102,6 @@ for it in range(rounds):
               f"exact-fp32 kernels vs oracle {np.abs(z32 - z_ref).max():.2e}, per structure " +
               " ".join(f"{np.abs(z_col[offs[j]:offs[j + 1]] - z_ref[offs[j]:offs[j + 1]]).max():.1e}" for j in range(len(structs))), flush=True)
     worst = max(worst, e)
-    assert e < 10 * TOL, ("collated", it, sizes, e)
+    assert e < TOL, ("collated", it, sizes, e)
     print(f"round {it}: sizes {sizes}  max |hip - oracle| so far {worst:.2e}", flush=True)
 print(f"{TAG}: {rounds} rounds ok in {time.time() - t0:.0f} s, max |hip - oracle| = {worst:.2e}; fp32 re-runs {m.status()['n_fp32_rerun']}")

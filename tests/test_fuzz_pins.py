@@ -1,0 +1,128 @@
+"""Pins of the randomised parity sweep (tests/golden/fuzz_pins.npz, written by tests/golden/make_fuzz_pins.py from the imported reference).
+
+Round 3's sweep (profiles/fuzz_vs_oracle.py) saw |hip - oracle| = 5.2e-4 and 3.1e-4 on two inputs, above the north-star's 1e-4. The
+generator replays that sweep, recovers both inputs and runs the REFERENCE on them in fp32 (1 and 8 threads) and fp64:
+  (a) collated batch [1023, 2000, 2 atoms] (the 2-atom member: 62 of 64 neighbour slots wrap, src/model_operations.py:8):
+      reference fp32 vs fp64 1.15e-4 (1 vs 8 threads: 5.9e-5), |z| up to 14.8, states |p| ~ 50 at layer 15;
+  (b) 500 atoms with a neighbour table of k = 8 columns zero-padded to 64 (:230): reference fp32 vs fp64 9.2e-5.
+Both are ill-conditioned for ANY fp32 evaluation (10x the 1e-5 spread of protein inputs). The round-3 deviation was the CHECKER's: the
+oracle's sequential float32 sums are 2 - 3x noisier per layer than the reference's blocked kernels there (oracle vs fp64: 6.9e-4 /
+2.5e-4); its wide build (double accumulators, float32 storage) is within 4.5e-5 / 2.1e-5 of the fp64 reference.
+Bound used here, as the round-3 verdict set it: |x - reference_fp64| <= max(1e-4, 2 |reference_fp32 - reference_fp64|); the seeded
+fuzz leg holds the plain 1e-4 wherever the reference's own spread is below 1e-5.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, onehot, weights
+from pesto_amd.config import CONFIGS
+
+TAG = "i_v4_0"
+
+
+def bound(z32, z64):
+    return max(1e-4, 2.0 * float(np.abs(z32 - z64).max()))
+
+
+def pinned(pre):
+    g = golden("fuzz_pins")
+    roa = g[pre + "roa"].astype(np.int32)
+    return dict(X=g[pre + "X"], ids=g[pre + "ids"].astype(np.int32), q0=onehot(g[pre + "q"][:, None], 30), roa=roa, R=int(roa.max()) + 1,
+                z32=g[pre + "z32_t8"], z32_t1=g[pre + "z32_t1"], z64=g[pre + "z64"])
+
+
+def leg_round(it):
+    """One round of the seeded fuzz leg: the collated batch (the reference's collate_batch_features output) and its members in the
+    per-structure contract (0-based ids with the structure's own k columns), with the reference's fp32 / fp64 logits for both forms."""
+    g = golden("fuzz_pins")
+    pre = f"leg{it}_"
+    X, ids, q, roa = g[pre + "X"], g[pre + "ids"].astype(np.int32), g[pre + "q"], g[pre + "roa"].astype(np.int32)
+    sizes, ks = g[pre + "sizes"], g[pre + "k"]
+    structs, a0, r0 = [], 0, 0
+    for (n, R), k in zip(sizes, ks):
+        n, R, k = int(n), int(R), int(k)
+        M = np.zeros((n, R), np.float32)
+        M[np.arange(n), roa[a0:a0 + n] - r0] = 1.0
+        structs.append((X[a0:a0 + n], np.ascontiguousarray(ids[a0:a0 + n, :k] - a0 - 1), onehot(q[a0:a0 + n, None], 30), M))
+        a0 += n; r0 += R
+    roffs = np.concatenate([[0], np.cumsum(sizes[:, 1])]).astype(int)
+    return dict(X=X, ids=ids, q0=onehot(q[:, None], 30), roa=roa, R=int(roffs[-1]), structs=structs, roffs=roffs,
+                col_z32=g[pre + "col_z32"], col_z64=g[pre + "col_z64"], ind_z32=g[pre + "ind_z32"], ind_z64=g[pre + "ind_z64"])
+
+
+# ------------------------------------------------------------------ CPU: the oracle (both builds) against the reference's fp64 logits
+@pytest.mark.parametrize("pre", ["a_", "b_"])
+def test_oracle_on_the_two_pinned_inputs(pre):
+    from oracle import oracle
+    p = pinned(pre)
+    wide = oracle.OracleModel(CONFIGS[TAG], weights(TAG), wide=True).forward_segments(p["X"], p["ids"], p["q0"], p["roa"], p["R"])
+    assert np.abs(wide - p["z64"]).max() <= bound(p["z32"], p["z64"])
+    assert np.abs(wide - p["z64"]).max() < 1e-4          # (measured 4.5e-5 / 2.1e-5: closer to fp64 than the reference's own fp32 run)
+    # the float32-accumulating port is the noisy one on these inputs (6.9e-4 / 2.5e-4): that, not the kernels, was round 3's deviation
+    plain = oracle.OracleModel(CONFIGS[TAG], weights(TAG)).forward_segments(p["X"], p["ids"], p["q0"], p["roa"], p["R"])
+    assert np.abs(plain - p["z64"]).max() < 2e-3
+
+
+@pytest.mark.parametrize("it", [0, 1, 2])
+def test_oracle_on_the_seeded_fuzz_leg(it):
+    from oracle import oracle
+    L = leg_round(it)
+    for wide in (False, True):
+        o = oracle.OracleModel(CONFIGS[TAG], weights(TAG), wide=wide)
+        z = o.forward_segments(L["X"], L["ids"], L["q0"], L["roa"], L["R"])
+        for j in range(len(L["structs"])):
+            sl = slice(L["roffs"][j], L["roffs"][j + 1])
+            spread = float(np.abs(L["col_z32"][sl] - L["col_z64"][sl]).max())
+            tol = 1e-4 if spread < 1e-5 else max(1e-4, 2 * spread)
+            assert np.abs(z[sl] - L["col_z64"][sl]).max() <= tol, (it, j, wide)
+
+
+# ------------------------------------------------------------------ GPU: the HIP path against the reference's fp64 logits
+def _model(precision="auto"):
+    from pesto_amd import Model
+    m = Model(CONFIGS[TAG], precision=precision)
+    m.load_state_dict(weights(TAG))
+    return m.eval()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pre", ["a_", "b_"])
+@pytest.mark.parametrize("precision", ["auto", "fp32"])
+def test_hip_on_the_two_pinned_inputs(pre, precision):
+    p = pinned(pre)
+    m = _model(precision)
+    z = m.forward_segments(p["X"], p["ids"], p["q0"], p["roa"], p["R"])      # the collated call, as the reference ran it
+    err = float(np.abs(z - p["z64"]).max())
+    print(f"\n   pinned {pre} {precision}: |hip - reference fp64| {err:.2e}, |hip - reference fp32| {np.abs(z - p['z32']).max():.2e}, "
+          f"reference fp32 vs fp64 {np.abs(p['z32'] - p['z64']).max():.2e}, bound {bound(p['z32'], p['z64']):.2e}")
+    assert err <= bound(p["z32"], p["z64"])
+    assert m.status()["n_fp32_rerun"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("it", [0, 1, 2])
+def test_hip_seeded_fuzz_leg(it):
+    """Three seeded rounds of ragged batches (2 - 1,025 atoms incl. 63 / 64 / 65 / 66, neighbour tables of 3 - 64 columns, residues of
+    1 - 30 atoms, permuted residue columns): COLLATED vs the reference's collated forward, INDEPENDENT vs the reference's one call per
+    structure, both at 1e-4 where the reference's own fp32-vs-fp64 spread is below 1e-5 (else 2 x that spread); and INDEPENDENT ==
+    one call per structure == the pipelined submit / wait path, bit for bit."""
+    L = leg_round(it)
+    m = _model()
+    z_col = m.forward_segments(L["X"], L["ids"], L["q0"], L["roa"], L["R"])
+    z_ind = m.forward_batch(L["structs"], independent=True)
+    z_pipe = m.forward_batch_wait(m.forward_batch_submit(L["structs"], independent=True))
+    z_colb = np.concatenate(m.forward_batch(L["structs"], independent=False), 0)
+    assert np.array_equal(z_col, z_colb)                      # device collate == the reference's collate_batch_features
+    worst = 0.0
+    for j, st in enumerate(L["structs"]):
+        sl = slice(L["roffs"][j], L["roffs"][j + 1])
+        for name, z, z32, z64 in (("collated", z_col[sl], L["col_z32"][sl], L["col_z64"][sl]), ("independent", z_ind[j], L["ind_z32"][sl], L["ind_z64"][sl])):
+            spread = float(np.abs(z32 - z64).max())
+            tol = 1e-4 if spread < 1e-5 else max(1e-4, 2 * spread)
+            err = float(np.abs(z - z64).max())
+            worst = max(worst, err)
+            assert err <= tol, (it, j, name, st[0].shape[0], err, spread)
+        single = m.forward_batch([st], independent=True)[0]
+        assert np.array_equal(z_ind[j], single) and np.array_equal(z_pipe[j], single), ("bitwise", it, j)
+    print(f"\n   fuzz leg round {it}: max |hip - reference fp64| = {worst:.2e}")
+    assert m.status()["n_fp32_rerun"] == 0
