@@ -43,18 +43,22 @@ typedef enum pesto_status {
  *               ~22-bit mantissa, but the f16 EXPONENT range - activations beyond +-65504 cannot be represented. The kernels
  *               detect that (range guard); the result is then NaN everywhere and, where the call synchronises, PESTO_ERR_RANGE.
  *   FP32      : everything on exact fp32 MFMA (v_mfma_f32_16x16x4_f32), no range limit, about half the speed.
- *   AUTO      : F16_SPLIT, and a forward whose range guard fired is repeated on the FP32 kernels (the reference's trained i_v3_1,
- *               model/save/i_v3_1_2021-05-28_12-40, needs this: its states reach 4e5). Default.
- *               Host-pointer calls (which wait for their D2H copy anyway) repeat before they return. Device-pointer calls stay
- *               ASYNCHRONOUS: the flags word is copied to pinned memory behind the launch and looked at by the NEXT call on the handle
- *               (any forward, pesto_postprocess, pesto_get_status, pesto_set_precision, pesto_synchronize): bad inputs are reported
- *               there (PESTO_ERR_INVALID), a range overflow queues the fp32 repeat of the remembered launch into the same z_out - so
- *               the caller keeps the buffers of an asynchronous call valid until that next call / pesto_synchronize returns. Until
- *               then an overflowed launch holds NaN logits (loud, never a plausible wrong number). After one overflow the handle runs
- *               the FP32 kernels first (no repeat per call) until pesto_set_precision is called again.
- *               Grouping caveat: the repeat is per LAUNCH, so under AUTO a structure that shares a launch with an overflowing one is
- *               computed on the fp32 kernels, alone on the split kernels - bitwise independence of the grouping
- *               (PESTO_BATCH_INDEPENDENT) holds for F16_SPLIT / FP32, and for AUTO while no launch is repeated. */
+ *   AUTO      : F16_SPLIT, and every STRUCTURE whose range guard fired is computed again on the FP32 kernels (the reference's trained
+ *               i_v3_1, model/save/i_v3_1_2021-05-28_12-40, needs this: its states reach 4e5). Default.
+ *               The guard is kept per structure of a launch (one word per member of a PESTO_BATCH_INDEPENDENT batch / per trajectory
+ *               frame / per collated call): the repeat runs the exact kernels over the launch again but writes only the logits of
+ *               the flagged structures; the others keep the logits of the split kernels. A structure's bits therefore do not depend
+ *               on what shared its launch - bitwise independence of the grouping holds under AUTO as under F16_SPLIT / FP32 -
+ *               and not on the handle's history either (no "fp32 first after one overflow" switch: a model that overflows on every
+ *               input pays the repeat every time; pesto_get_status counts the structures repeated - use PESTO_PRECISION_FP32 for it).
+ *               Host-pointer calls (which wait for their D2H copy anyway) repeat before they return. Device-pointer calls also
+ *               CHECK BEFORE THEY RETURN (one 4-byte D2H + a stream synchronisation behind the launch), so z_out is final when a
+ *               drop-in caller consumes it with further stream work. pesto_set_async_auto(m, 1) trades that for a fully asynchronous
+ *               call: the flags word is copied to pinned memory behind the launch and looked at by the NEXT call on the handle (any
+ *               forward, pesto_postprocess, pesto_get_status, pesto_set_precision, pesto_forward_batch_wait, pesto_synchronize):
+ *               bad inputs are reported there (PESTO_ERR_INVALID), a range overflow queues the fp32 repeat of the remembered launch
+ *               into the same z_out - the caller keeps the buffers of such a call valid until that next call / pesto_synchronize
+ *               returns; until then the structures of an overflowed launch hold NaN logits (loud, never a plausible wrong number). */
 typedef enum pesto_precision {
     PESTO_PRECISION_AUTO = 0,
     PESTO_PRECISION_F16_SPLIT = 1,
@@ -90,16 +94,20 @@ int pesto_create(const pesto_config* cfg, const float* weights, int64_t n_weight
 int pesto_destroy(pesto_model* m);
 
 /* change the precision policy of an existing handle (takes effect with the next call) / read it back together with the number
- * of launch sequences run so far and how many of them AUTO repeated on the fp32 kernels */
+ * of launch sequences run so far and how many STRUCTURES AUTO computed again on the fp32 kernels */
 int pesto_set_precision(pesto_model* m, int32_t precision);
 int pesto_get_status(const pesto_model* m, int32_t* precision, int64_t* n_forward, int64_t* n_fp32_rerun);
+/* enabled != 0: device-pointer forwards under PESTO_PRECISION_AUTO return without synchronising; their range / input check is made by
+ * the next call on the handle (see pesto_precision). Default 0: checked before the call returns. No reference counterpart. */
+int pesto_set_async_auto(pesto_model* m, int32_t enabled);
 
 /* replaces: Model.forward(X, ids_topk, q0, M)  (model/model.py:32-52).
  * ptr_kind: PESTO_PTR_HOST (library stages H2D/D2H itself) or PESTO_PTR_DEVICE (all five buffers on
  * the model's device). stream: a hipStream_t. With device pointers the work is queued on exactly that stream
- * (NULL = HIP's default stream, which is what torch.cuda.current_stream() is by default) and the call returns at once: under
- * PESTO_PRECISION_AUTO the flags word (bad ids / residue columns, range overflow) is checked by the next call on the handle
- * (see pesto_precision above); under F16_SPLIT / FP32 nothing is checked (bad inputs or an overflow make every logit NaN).
+ * (NULL = HIP's default stream, which is what torch.cuda.current_stream() is by default). Under PESTO_PRECISION_AUTO the flags word
+ * (bad ids / residue columns, range overflow) is read back behind the launch and the call returns once it has been checked
+ * (pesto_set_async_auto(m, 1): returns at once, checked by the next call on the handle - see pesto_precision above); under
+ * F16_SPLIT / FP32 the call returns at once and nothing is checked (bad inputs make every logit NaN, an overflow its structure's).
  * With host pointers NULL selects the model's own stream, the call returns after z has been copied back, and the checks
  * (PESTO_ERR_INVALID, the fp32 repeat under AUTO, PESTO_ERR_RANGE under F16_SPLIT) happen before it returns.
  * A handle owns ONE workspace: calls on different streams are ordered after one another through an event, never concurrent.
@@ -180,8 +188,8 @@ int pesto_forward_batch_wait(pesto_model* m, int32_t ticket);
 /* bytes of device workspace a batch of (N, R) needs (ownership: SURVEY 8b) */
 int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* bytes);
 
-/* wait for everything queued on the model's own stream; also runs the deferred check of the last asynchronous AUTO launch (its
- * error code is returned; an overflowed launch is repeated on the fp32 kernels and waited for) */
+/* wait for everything queued on the model's own stream; also runs the deferred check of the last asynchronous AUTO launch
+ * (pesto_set_async_auto; its error code is returned; the structures of an overflowed launch are repeated on the fp32 kernels and waited for) */
 int pesto_synchronize(pesto_model* m);
 
 /* mean duration in milliseconds of the state-update kernels of the most recent pesto_forward, measured with

@@ -61,6 +61,7 @@ ABI_SYMBOLS = [
     "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch", "pesto_get_kernel_timing",
     "pesto_set_precision", "pesto_get_status", "pesto_debug_select", "pesto_forward_structures",
     "pesto_mask_to_segments", "pesto_debug_edge_mode", "pesto_forward_batch_submit", "pesto_forward_batch_wait",
+    "pesto_set_async_auto",
 ]
 
 _lib = None
@@ -102,6 +103,7 @@ def load():
     lib.pesto_forward_batch_submit.argtypes = [c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p, i32, c_p, c_p, c_p, i32, P(i32)]
     lib.pesto_forward_batch_wait.argtypes = [c_p, i32]
     lib.pesto_set_precision.argtypes = [c_p, i32]
+    lib.pesto_set_async_auto.argtypes = [c_p, i32]
     lib.pesto_get_status.argtypes = [c_p, P(i32), P(i64), P(i64)]
     lib.pesto_debug_select.argtypes = [c_p, i32, i32]
     lib.pesto_debug_edge_mode.argtypes = [c_p, i32]

@@ -53,6 +53,22 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
     n0 = model.config["em"]["N0"]
     dev = torch.device("cuda", model._gpu)
     results = {}
+    # launches stay asynchronous (pesto_set_async_auto): the post-op of a launch - the next call on the handle - makes its deferred range /
+    # input check, so the host packs, slices and writes while the GPU computes
+    was_async = model.async_auto
+    model.set_async_auto(True)
+    try:
+        _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_error, results, dev, n0)
+    finally:
+        model.synchronize()
+        model.set_async_auto(was_async)
+    if results_path is not None:
+        save_results(results, results_path)
+    return results
+
+
+def _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_error, results, dev, n0):
+    import torch
     with ThreadPoolExecutor(max_workers=workers) as pool:
         loads = [(p, pool.submit(_load, p, n0)) for p in pdb_filepaths]
         writes = []
@@ -117,6 +133,3 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
         hand_out(fetch())
         for w in writes:
             w.result()
-    if results_path is not None:
-        save_results(results, results_path)
-    return results

@@ -65,7 +65,10 @@ struct pesto_model {
     int edge_blocks = 512;                 // persistent workgroups of the edge kernel (2 per CU)
     bool knn_brute = false;                // pesto_debug_select: brute-force k-NN for every structure
     int edge_mode = 0;                     // pesto_debug_edge_mode: 0 = per launch, 1 = rendezvous, 2 = node waves
-    int64_t n_forward = 0, n_rerun = 0;    // launch sequences run / repeated on the exact fp32 kernels after a range overflow
+    int64_t n_forward = 0, n_rerun = 0;    // launch sequences run / STRUCTURES repeated on the exact fp32 kernels after a range overflow
+    DevBuf sflags;                         // range guard: one word per structure (frame) of the launch (SatCtx)
+    std::vector<int> h_sflags;             // host copy (counting the structures a repeat covers)
+    bool async_auto = false;               // pesto_set_async_auto: device-pointer calls under AUTO defer their check to the next call
     // every launch sequence uses the ONE workspace below: sequences on different streams are ordered through this event
     hipEvent_t ws_ev = nullptr;
     hipStream_t ws_stream = nullptr;
@@ -75,7 +78,6 @@ struct pesto_model {
     // looked at by the NEXT call on the handle (resolve_pending): bad inputs are reported there, a range overflow repeats the
     // remembered launch on the exact fp32 kernels (its buffers must still be valid) and makes the handle run fp32 first from then on
     struct Pending { bool active = false; hipStream_t st = nullptr; hipEvent_t ev = nullptr; void* args = nullptr; } pend;   // args: FwdArgs of the launch
-    bool auto_fp32 = false;                // AUTO has seen an overflow: exact kernels first (cleared by pesto_set_precision)
     DevBuf col_seg, col_segend;            // pesto_forward_batch: structure of every atom, end offset of every structure
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     DevBuf in_M, mask_seen;               // pesto_mask_to_segments: host mask staging, one word per residue column
@@ -90,6 +92,7 @@ struct pesto_model {
         void* h_in = nullptr; size_t h_cap = 0;         // pinned: [meta | X | ids | q | roa] of the launch, one H2D copy
         float* h_z = nullptr; size_t hz_cap = 0;         // pinned: the logits of the launch
         int* h_flag = nullptr;                           // pinned: the flags word
+        int* h_sflags = nullptr; size_t hs_cap = 0;      // pinned: the per-structure range-guard words of the launch
         DevBuf d_in, d_z;
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
         bool busy = false;
@@ -206,7 +209,9 @@ struct FwdArgs {
 
 // the launch sequence of Model.forward (model/model.py:32-52) on stream st
 // exact: the state-update layers on the exact fp32 MFMA kernels instead of the f16-split ones
-int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
+// masked (exact only): the fp32 repeat of PESTO_PRECISION_AUTO - the per-structure guard words of the launch being repeated are in place
+// (m->sflags, not cleared) and only the logits of the structures whose word is set are written
+int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bool masked = false) {
     const int64_t NT = a.N * a.F, RT = a.R * a.F;
     const int N1 = (int)NT + 1;
     const int edge_variant = exact ? 1 : 0;
@@ -216,7 +221,8 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     // per-forward words cleared by ONE memset: [max(D) bit patterns, n_dmax | segment bounds of the pool layer: lo_enc RT, hi RT]
     const size_t seg_off = (n_dmax + 3) / 4 * 4;      // (in ints)
     const size_t clear_bytes = ((seg_off + 2 * (size_t)RT) * 4 + 63) / 64 * 64;      // (a multiple of 64 bytes: one fill kernel, no tail launch)
-    if (m->dmax.ensure(clear_bytes)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    if (m->dmax.ensure(clear_bytes) || m->sflags.ensure(n_dmax * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    const SatCtx sc{err_ptr(m), m->sflags.as<int>(), a.seg_of_atom, (!a.seg_of_atom && a.F > 1) ? (int)a.N : 0};
     int* seg_lo = m->dmax.as<int>() + seg_off;
     int* seg_hi = seg_lo + RT;
     const bool bounds_in_embed = a.F == 1;             // found by the unpack launch (trajectory batches expand res_of_atom per frame behind it: separate launches)
@@ -232,7 +238,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
     SegBoundsArgs sb;
     if (bounds_in_embed) sb = SegBoundsArgs{a.roa, seg_lo, seg_hi, (int)RT, err_ptr(m)};
     launch_embed(st, m->W, m->img.model.em, (int)NT, (int)a.N, m->cfg.n0, a.q0, q[0], p[0],      // also p0 = zeros and the sink rows (model.py:37, model_operations.py:17)
-                 ClearArgs{m->flags.as<int>(), 2, m->dmax.as<int>(), (int)(clear_bytes / 4)});
+                 ClearArgs{m->flags.as<int>(), 2, m->dmax.as<int>(), (int)(clear_bytes / 4), m->sflags.as<int>(), masked ? 0 : (int)n_dmax}, sc);
     launch_unpack(st, (int)a.N, (int)a.F, a.k, a.X, a.xs_frame, a.xs_atom, a.ids, a.ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(),
                   dmax_ptr(m), err_ptr(m), a.seg_of_atom, a.seg_end, sb);
     if (a.F > 1) launch_expand_roa(st, (int)a.N, (int)a.R, (int)a.F, a.roa, m->roa_f.as<int>(), err_ptr(m));
@@ -320,28 +326,45 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact) {
         m->have_timing = true;
     }
     launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)NT, (int)RT, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
-                seg_lo, seg_hi, err_ptr(m), nullptr, nullptr, a.z_out, bounds_in_embed);
+                seg_lo, seg_hi, err_ptr(m), nullptr, nullptr, a.z_out, bounds_in_embed, sc, masked);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int check_model(const pesto_model* m) { return m ? 0 : fail(PESTO_ERR_INVALID, "null model handle"); }
 
+// number of structures (frames) of a launch = words of its range guard
+size_t n_guard_words(const FwdArgs& a) { return a.seg_of_atom ? (size_t)a.n_seg : (size_t)a.F; }
+
+// the fp32 repeat of a launch whose range guard fired (PESTO_PRECISION_AUTO): the exact kernels run the whole launch again - its
+// per-structure guard words are still in m->sflags - and the pool kernel writes ONLY the logits of the flagged structures. The others
+// keep the logits of the split kernels, so a structure's bits do not depend on what shared its launch. Counts the structures repeated.
+int rerun_flagged(pesto_model* m, hipStream_t st, const FwdArgs& a) {
+    const size_t n = n_guard_words(a);
+    m->h_sflags.assign(n, 0);
+    HIP_TRY(hipMemcpyAsync(m->h_sflags.data(), m->sflags.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; ++i) m->n_rerun += (m->h_sflags[i] & 4) ? 1 : 0;
+    return run_forward(m, st, a, true, true);
+}
+
 // One forward under the handle's precision policy, then flag handling.
-//   FP32      : exact kernels. F16_SPLIT: split kernels. AUTO: split kernels; if the range guard fired, the same inputs again
-//               on the exact kernels (the inputs are still in place).
-//   sync_check: read the flags word back (synchronises st) and turn bad inputs / a range overflow into an error code. Host-pointer
-//               calls always do (they wait for the D2H copy anyway; `after_run` queues that copy). Device-pointer calls do in
-//               AUTO mode only - F16_SPLIT and FP32 stay asynchronous and unchecked there (bad inputs or an overflow still make
-//               every logit NaN, written by the pool kernel).
+//   FP32      : exact kernels. F16_SPLIT: split kernels. AUTO: split kernels; the structures whose range guard fired are computed
+//               again on the exact kernels (rerun_flagged; the inputs are still in place).
+//   sync_check: read the flags word back (synchronises st) and turn bad inputs / a range overflow into an error code / the repeat.
+//               Host-pointer calls always do (they wait for the D2H copy anyway; `after_run` queues that copy). Device-pointer calls
+//               do in AUTO mode - F16_SPLIT and FP32 stay asynchronous and unchecked there (bad inputs make every logit NaN, an
+//               overflow the logits of its structure: written by the pool kernel).
+//   defer     : AUTO with device pointers on a handle with pesto_set_async_auto(m, 1): no synchronisation, the check is made by the
+//               next call on the handle (resolve_pending).
 template <typename AfterRun>
 int forward_policy(pesto_model* m, hipStream_t st, const FwdArgs& a, bool sync_check, AfterRun after_run, bool defer = false) {
-    const bool exact_first = m->precision == PESTO_PRECISION_FP32 || m->impl != 2 || (m->precision == PESTO_PRECISION_AUTO && m->auto_fp32);
+    const bool exact_first = m->precision == PESTO_PRECISION_FP32 || m->impl != 2;
     if (int rc = run_forward(m, st, a, exact_first)) return rc;
     if (int rc = after_run()) return rc;
-    if (defer && m->precision == PESTO_PRECISION_AUTO) {
-        // device pointers: no host synchronisation. The flags word travels to pinned memory behind the launch; the next call on the
-        // handle looks at it (resolve_pending). Until then an overflowed launch has NaN logits (written by the pool kernel).
+    if (defer && m->precision == PESTO_PRECISION_AUTO && !exact_first) {
+        // the flags word travels to pinned memory behind the launch; until the next call on the handle has looked at it, the
+        // structures of an overflowed launch hold NaN logits (written by the pool kernel)
         if (!m->pend.ev) HIP_TRY(hipEventCreateWithFlags(&m->pend.ev, hipEventDisableTiming));
         HIP_TRY(hipMemcpyAsync(m->h_flags + 8, err_ptr(m), sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(m->pend.ev, st));
@@ -356,9 +379,7 @@ int forward_policy(pesto_model* m, hipStream_t st, const FwdArgs& a, bool sync_c
     const bool may_rerun = m->precision == PESTO_PRECISION_AUTO && !exact_first;
     if (int rc = check_device_flag(m, st, &flag, may_rerun ? 4 : 0)) return rc;
     if ((flag & 4) && may_rerun) {
-        m->n_rerun += 1;
-        m->auto_fp32 = true;
-        if (int rc = run_forward(m, st, a, true)) return rc;
+        if (int rc = rerun_flagged(m, st, a)) return rc;
         if (int rc = after_run()) return rc;
         return check_device_flag(m, st);
     }
@@ -376,13 +397,12 @@ int resolve_pending(pesto_model* m) {
     if (flag & 2) return fail(PESTO_ERR_INVALID, "the previous (asynchronous) forward had an index of res_of_atom outside [0, R) (from pesto_mask_to_segments: "
                                                "a row of M with != 1 member or an empty residue column): its logits are NaN");
     if (flag & 4) {
-        // repeat it on the exact kernels, on its own stream, into the same z (the caller keeps the buffers of an asynchronous call
-        // valid until the next call on the handle or pesto_synchronize returns)
-        m->n_rerun += 1;
-        m->auto_fp32 = true;
+        // repeat the flagged structures on the exact kernels, on the launch's own stream, into the same z (the caller keeps the buffers
+        // of an asynchronous call valid until the next call on the handle or pesto_synchronize returns; the launch's guard words and
+        // structure table are still in the workspace: nothing has been queued on the handle since)
         Sequence seq(m, m->pend.st);
         if (seq.rc) return seq.rc;
-        if (int rc = run_forward(m, m->pend.st, *static_cast<FwdArgs*>(m->pend.args), true)) return rc;
+        if (int rc = rerun_flagged(m, m->pend.st, *static_cast<FwdArgs*>(m->pend.args))) return rc;
     }
     return 0;
 }
@@ -442,6 +462,7 @@ int pesto_destroy(pesto_model* m) {
         if (b.h_in) (void)hipHostFree(b.h_in);
         if (b.h_z) (void)hipHostFree(b.h_z);
         if (b.h_flag) (void)hipHostFree(b.h_flag);
+        if (b.h_sflags) (void)hipHostFree(b.h_sflags);
         b.d_in.release(); b.d_z.release();
     }
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
@@ -453,7 +474,7 @@ int pesto_destroy(pesto_model* m) {
     for (auto& e : m->kev) if (e) (void)hipEventDestroy(e);
     if (m->W) (void)hipFree(m->W);
     for (DevBuf* b : {&m->ids_s, &m->geo, &m->q_a, &m->p_a, &m->q_b, &m->p_b, &m->pool_a, &m->seg, &m->z, &m->flags,
-                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->rec_nb2, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa, &m->knn_grids, &m->knn_cnt, &m->knn_cur, &m->knn_cell, &m->knn_sorted, &m->col_seg, &m->col_segend, &m->in_M, &m->mask_seen})
+                      &m->in_X, &m->in_ids, &m->in_q0, &m->in_roa, &m->rec_nb, &m->rec_cen, &m->rec_nb2, &m->zrec, &m->knn_off, &m->dmax, &m->roa_f, &m->col_meta, &m->col_ids, &m->col_roa, &m->knn_grids, &m->knn_cnt, &m->knn_cur, &m->knn_cell, &m->knn_sorted, &m->col_seg, &m->col_segend, &m->in_M, &m->mask_seen, &m->sflags})
         b->release();
     delete m;
     return 0;
@@ -483,7 +504,13 @@ int pesto_set_precision(pesto_model* m, int32_t precision) {
         return fail(PESTO_ERR_INVALID, "precision must be PESTO_PRECISION_AUTO, _F16_SPLIT or _FP32");
     if (int rc = resolve_pending(m)) return rc;
     m->precision = precision;
-    m->auto_fp32 = false;
+    return 0;
+}
+
+int pesto_set_async_auto(pesto_model* m, int32_t enabled) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;
+    m->async_auto = enabled != 0;
     return 0;
 }
 
@@ -610,9 +637,10 @@ int forward_common(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_fr
             a.F = (c + 1) * n_frames / n_chunks - f0;
             a.X = X + f0 * x_frame_stride;
             a.z_out = z_out + f0 * R * n_out;
-            // AUTO: asynchronous, checked by the next call (a multi-chunk frame call checks every chunk but the last right here)
-            if (c + 1 < n_chunks) { if (int rc = forward_policy(m, st, a, m->precision == PESTO_PRECISION_AUTO, [] { return 0; })) return rc; }
-            else if (int rc = forward_policy(m, st, a, false, [] { return 0; }, true)) return rc;
+            // AUTO: checked before the call returns (one 4-byte D2H + a stream synchronisation); on a handle with pesto_set_async_auto the
+            // last chunk is left to the next call on the handle instead (every other chunk of a multi-chunk frame call is checked here)
+            const bool last = c + 1 == n_chunks;
+            if (int rc = forward_policy(m, st, a, m->precision == PESTO_PRECISION_AUTO, [] { return 0; }, last && m->async_auto)) return rc;
         }
         return 0;
     }
@@ -735,9 +763,13 @@ struct CollMeta { int off, roff, n, r, k; long long idoff; };
 size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 // the device half of one staged launch on the compute stream: (one-hot expansion,) collate, forward, logits + flags to pinned memory
-int queue_slot(pesto_model* m, pesto_model::BatchSlot& b, hipStream_t st, bool exact) {
+int queue_slot(pesto_model* m, pesto_model::BatchSlot& b, hipStream_t st, bool exact, bool masked = false) {
     Sequence seq(m, st);
     if (seq.rc) return seq.rc;
+    const size_t n_words = b.mode == PESTO_BATCH_INDEPENDENT ? (size_t)b.n_struct : 1;
+    if (m->sflags.ensure(n_words * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    // masked repeat: the guard words of THIS launch back into the workspace (another slot's launch has used it in between)
+    if (masked) HIP_TRY(hipMemcpyAsync(m->sflags.p, b.h_sflags, n_words * 4, hipMemcpyHostToDevice, st));
     char* base = (char*)b.d_in.p;
     HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
     const float* q0 = (const float*)(base + b.off_q);
@@ -754,9 +786,10 @@ int queue_slot(pesto_model* m, pesto_model::BatchSlot& b, hipStream_t st, bool e
     // run_forward clears the flags word itself: the collate / one-hot checks are repeated by the forward's own validation of ids and
     // residue columns (a bad index reaches it as index 0 + the flag, which the memset would lose) - keep the flag by OR-ing it back
     HIP_TRY(hipMemcpyAsync(m->flags.as<int>() + 2, err_ptr(m), sizeof(int), hipMemcpyDeviceToDevice, st));
-    if (int rc = run_forward(m, st, a, exact)) return rc;
+    if (int rc = run_forward(m, st, a, exact, masked)) return rc;
     HIP_TRY(hipMemcpyAsync(b.h_z, b.d_z.p, (size_t)b.RT * m->cfg.n_out * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(b.h_flag, m->flags.as<int>() + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, st));     // [forward's flags, collate's flags]
+    if (!masked) HIP_TRY(hipMemcpyAsync(b.h_sflags, m->sflags.p, n_words * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(b.ev_done, st));
     return 0;
 }
@@ -796,6 +829,12 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
     if (!m->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
     if (!b.ev_h2d) { HIP_TRY(hipEventCreateWithFlags(&b.ev_h2d, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming)); }
     if (!b.h_flag) HIP_TRY(hipHostMalloc((void**)&b.h_flag, 64, hipHostMallocDefault));
+    if ((size_t)n_struct > b.hs_cap) {
+        if (b.h_sflags) HIP_TRY(hipHostFree(b.h_sflags));
+        b.h_sflags = nullptr; b.hs_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&b.h_sflags, ((size_t)n_struct + 64) * 4, hipHostMallocDefault));
+        b.hs_cap = (size_t)n_struct + 64;
+    }
     // blob layout: [meta | X | ids | q (dense floats or index bytes) | roa], every part 16-byte aligned
     const size_t sz_meta = align16(meta.size() * sizeof(CollMeta));
     b.off_X = sz_meta;
@@ -837,7 +876,7 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
     HIP_TRY(hipMemcpyAsync(b.d_in.p, b.h_in, total, hipMemcpyHostToDevice, m->copy_stream));
     HIP_TRY(hipEventRecord(b.ev_h2d, m->copy_stream));
     HIP_TRY(hipStreamWaitEvent(m->stream, b.ev_h2d, 0));
-    const bool exact = m->precision == PESTO_PRECISION_FP32 || m->impl != 2 || (m->precision == PESTO_PRECISION_AUTO && m->auto_fp32);
+    const bool exact = m->precision == PESTO_PRECISION_FP32 || m->impl != 2;
     if (int rc = queue_slot(m, b, m->stream, exact)) return rc;
     b.busy = true;
     *ticket = m->next_slot;
@@ -849,9 +888,10 @@ int pesto_forward_batch_wait(pesto_model* m, int32_t ticket) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     if (ticket < 0 || ticket > 1 || !m->slot[ticket].busy) return fail(PESTO_ERR_STATE, "no launch in flight under ticket %d", ticket);
     pesto_model::BatchSlot& b = m->slot[ticket];
+    if (int rc = resolve_pending(m)) return rc;      // (its repeat reads workspace words a repeat queued below would overwrite)
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipEventSynchronize(b.ev_done));
-    b.busy = false;
+    struct Release { bool& busy; ~Release() { busy = false; } } release{b.busy};      // the slot is free once this call has no work queued on it
     int flag = b.h_flag[0] | b.h_flag[1];
     if (flag & 1) return fail(PESTO_ERR_INVALID, "ids_topk (or a feature index) contains an index outside its range");
     if (flag & 2) return fail(PESTO_ERR_INVALID, "res_of_atom contains an index outside [0, R)");
@@ -859,9 +899,10 @@ int pesto_forward_batch_wait(pesto_model* m, int32_t ticket) {
         const bool exact_first = m->precision == PESTO_PRECISION_FP32 || m->impl != 2;
         if (m->precision != PESTO_PRECISION_AUTO || exact_first)
             return fail(PESTO_ERR_RANGE, "an activation left the f16 range of the split-MFMA path (z is NaN): use PESTO_PRECISION_AUTO or PESTO_PRECISION_FP32");
-        m->n_rerun += 1;            // the slot's inputs are still on the device: repeat the launch on the exact fp32 kernels
-        m->auto_fp32 = true;
-        if (int rc = queue_slot(m, b, m->stream, true)) return rc;
+        // the slot's inputs are still on the device: the flagged structures again, on the exact fp32 kernels (the others keep their logits)
+        const size_t n_words = b.mode == PESTO_BATCH_INDEPENDENT ? (size_t)b.n_struct : 1;
+        for (size_t i = 0; i < n_words; ++i) m->n_rerun += (b.h_sflags[i] & 4) ? 1 : 0;
+        if (int rc = queue_slot(m, b, m->stream, true, true)) { (void)hipStreamSynchronize(m->stream); return rc; }
         HIP_TRY(hipEventSynchronize(b.ev_done));
         flag = b.h_flag[0] | b.h_flag[1];
         if (flag & 3) return fail(PESTO_ERR_INVALID, "bad inputs");
@@ -1058,7 +1099,12 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
     hipStream_t st = m->stream;
     Sequence seq(m, st);
     if (seq.rc) return seq.rc;
+    if (m->sflags.ensure(4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
     HIP_TRY(hipMemsetAsync(m->flags.p, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(m->sflags.p, 0, 4, st));
+    const SatCtx sc{err_ptr(m), m->sflags.as<int>(), nullptr, 0};      // (no embed launch here: the guard's context is uploaded)
+    HIP_TRY(hipMemcpyAsync(err_ptr(m) + SATCTX_OFFSET_INTS, &sc, sizeof sc, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpyAsync(m->q_a.p, q_io, N1 * S * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->p_a.p, p_io, N1 * 96 * 4, hipMemcpyHostToDevice, st));
     const void *q_res = m->q_b.p, *p_res = m->p_b.p;

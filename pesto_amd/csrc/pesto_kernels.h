@@ -10,10 +10,17 @@ namespace pesto {
 // p_zero (optional): [N + 1, 96] state array that is zeroed along the way (p0 = zeros), together with the sink row of q_state
 // optional extra job of the unpack launch: the residue segment bounds of the pool layer (lo_enc / hi zero-initialised before it)
 struct SegBoundsArgs { const int* roa = nullptr; int* lo_enc = nullptr; int* hi = nullptr; int R = 0; int* err_flag = nullptr; };
-// optional extra job of the embed launch (the first of a forward): clear two arrays of per-forward words (int counts)
-struct ClearArgs { int* p0 = nullptr; int n0 = 0; int* p1 = nullptr; int n1 = 0; };
+// optional extra job of the embed launch (the first of a forward): clear up to three arrays of per-forward words (int counts)
+struct ClearArgs { int* p0 = nullptr; int n0 = 0; int* p1 = nullptr; int n1 = 0; int* p2 = nullptr; int n2 = 0; };
+// range guard of the f16-split kernels, per structure: flags = the launch's flags word (bit 2: some activation left the f16 range),
+// sflags = one word per structure of the launch (same bit). Structure of state row i (1-based; 0 = sink): seg_of_atom[i - 1] for a
+// ragged batch with separate-call semantics, (i - 1) / frame_n for trajectory frames, 0 for a plain collated call (both null / 0).
+// The context lives in device memory SATCTX_OFFSET_INTS ints behind the flags word the layer kernels get (written by the embed launch,
+// the first of every forward): the kernels' hot paths carry no extra arguments, only the rare flagging path reads it.
+struct SatCtx { int* flags = nullptr; int* sflags = nullptr; const int* seg_of_atom = nullptr; int frame_n = 0; };
+constexpr int SATCTX_OFFSET_INTS = 3;      // flags buffer: [0] unused, [1] the flags word, [2] collate's copy, [3] pad, [4..] SatCtx (16-byte aligned)
 void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero = nullptr,
-                  ClearArgs clr = ClearArgs());
+                  ClearArgs clr = ClearArgs(), SatCtx sc = SatCtx());      // sc.flags non-null: the context is stored behind that word
 // F coordinate frames of Nf atoms sharing one ids table [Nf,k] (F = 1: a plain collated batch); X strides in floats;
 // dmax_bits[F] must be zeroed. seg_of_atom / seg_end (F = 1 only, may be null): ragged structures that must behave like separate
 // calls - per-structure wrap-around target and max(D); dmax_bits then holds one zeroed word per structure
@@ -24,7 +31,8 @@ void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int
 void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                      const float* q_in, const float* p_in, float* q_out, float* p_out);
 // MFMA layer (pesto_layer_mfma.hip): per-atom node kernel (finish previous layer / prepare records) + edge kernel.
-// flags: the error word; the f16-split kernels set bit 4 when an activation left the f16 range (sat_probe)
+// flags: the flags word (the SatCtx of the launch lies behind it); the f16-split kernels set bit 2 (value 4) of it and of the
+// structure's word when an activation left the f16 range (sat_probe)
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
                  const float* Z, float* rec_nb, float* rec_cen, int variant, int* flags);
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
@@ -57,8 +65,11 @@ void launch_segments(hipStream_t st, int n_total, int n_struct, const int* seg_e
 void launch_mask_to_segments(hipStream_t st, int N, int R, const float* M, int* roa, int* seen);
 void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z, const int* roa, float* p_out, float* bf_out, int* err_flag);
 void debug_print_phase_cycles();   // no-op unless built with -DPESTO_PROFILE_PHASES
+// sc (optional): a residue whose structure has its range-guard word set gets NaN logits; only_flagged: ONLY those residues are written
+// (the fp32 repeat of PESTO_PRECISION_AUTO: the other structures keep the logits of the split kernels)
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,
                  const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out,
-                 bool bounds_ready = false);      // bounds_ready: lo / hi already hold the segment bounds (launch_embed with SegBoundsArgs)
+                 bool bounds_ready = false,       // bounds_ready: lo / hi already hold the segment bounds (launch_embed with SegBoundsArgs)
+                 SatCtx sc = SatCtx(), bool only_flagged = false);
 
 }  // namespace pesto

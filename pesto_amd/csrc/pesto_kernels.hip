@@ -60,12 +60,14 @@ __device__ __forceinline__ void seg_bound_atom(int i, int R, const int* __restri
 // q[i+1][:] = em(q0[i][:]) ; 8 atoms per 256-thread block, 32 lanes per atom.  model/model.py:34
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW em, int N, int nq, int n0,
                                                const float* __restrict__ q0, float* __restrict__ q_state, float* __restrict__ p_zero,
-                                               ClearArgs clr) {
+                                               ClearArgs clr, SatCtx sc) {
     // the forward's per-call words (error flags, max(D) bit patterns, segment bounds of the pool layer) are cleared by workgroup 0
     // of this FIRST launch instead of by fill launches in front of it: nothing in this kernel reads or writes them otherwise
     if (blockIdx.x == 0) {
         for (int k = threadIdx.x; k < clr.n0; k += 256) clr.p0[k] = 0;
         for (int k = threadIdx.x; k < clr.n1; k += 256) clr.p1[k] = 0;
+        for (int k = threadIdx.x; k < clr.n2; k += 256) clr.p2[k] = 0;
+        if (sc.flags && threadIdx.x == 0) *reinterpret_cast<SatCtx*>(sc.flags + SATCTX_OFFSET_INTS) = sc;      // the range guard's context (pesto_kernels.h)
     }
     __shared__ __attribute__((aligned(16))) float xs[8][512];
     __shared__ __attribute__((aligned(16))) float hs[8][64];
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
                                                     const float* __restrict__ a, const int* __restrict__ roa,
                                                     const int* __restrict__ lo, const int* __restrict__ hi,
                                                     float* __restrict__ qr_out, float* __restrict__ pr_out,
-                                                    float* __restrict__ z_out, const int* __restrict__ flags) {
+                                                    float* __restrict__ z_out, const int* __restrict__ flags, SatCtx sc, int only_flagged) {
     __shared__ __attribute__((aligned(16))) float qh[128];
     __shared__ __attribute__((aligned(16))) float ph[3][128];
     __shared__ __attribute__((aligned(16))) float hs[64];
@@ -502,9 +504,15 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
     const int r = blockIdx.x;
     const int lane = threadIdx.x, s = lane & 31, hf = lane >> 5;
     const int i0 = 0x7fffffff - lo[r], i1 = hi[r];      // (lo is stored as 0x7fffffff - first member; an empty residue gives i0 > i1)
-    // bad ids / residue columns, or an activation beyond the f16 range on the split-MFMA path (flag bit 4): the result would be
-    // silently wrong (ELU maps the NaN of an overflowed product to 0), so it is made loud - every logit NaN
-    if (i0 >= i1 || (*flags & 7)) {   // (empty residue: the reference degenerates to a whole-batch softmax; NaN here)
+    // bad ids / residue columns: every logit NaN. An activation beyond the f16 range on the split-MFMA path (bit 2 of the word of the
+    // residue's STRUCTURE): the result would be silently wrong (ELU maps the NaN of an overflowed product to 0), so it is made loud -
+    // NaN for that structure's residues; the structures that stayed in range keep their logits
+    const bool bad = i0 >= i1 || (*flags & 3);      // (empty residue: the reference degenerates to a whole-batch softmax; NaN here)
+    bool ranged = false;
+    if (!bad && sc.sflags) ranged = (sc.sflags[sc.seg_of_atom ? sc.seg_of_atom[i0] : sc.frame_n ? i0 / sc.frame_n : 0] & 4) != 0;
+    if (only_flagged) {          // fp32 repeat: only the residues of the structures whose guard fired are (re)written
+        if (bad || !ranged) return;
+    } else if (bad || ranged) {
         if (lane < n_out) z_out[(size_t)r * n_out + lane] = __uint_as_float(0x7fc00000u);
         return;
     }
@@ -593,8 +601,8 @@ __global__ __launch_bounds__(64) void k_pool_reduce(const float* __restrict__ W,
 
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero,
-                  ClearArgs clr) {
-    hipLaunchKernelGGL(k_embed, dim3((N + 7) / 8), dim3(256), 0, st, W, em, N, nq, n0, q0, q_state, p_zero, clr);
+                  ClearArgs clr, SatCtx sc) {
+    hipLaunchKernelGGL(k_embed, dim3((N + 7) / 8), dim3(256), 0, st, W, em, N, nq, n0, q0, q_state, p_zero, clr, sc);
 }
 
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
@@ -617,14 +625,15 @@ void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int
 }
 
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,
-                 const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out, bool bounds_ready) {
+                 const int* roa, float* a_tmp, int* lo, int* hi, int* err_flag, float* qr_out, float* pr_out, float* z_out, bool bounds_ready,
+                 SatCtx sc, bool only_flagged) {
     if (!bounds_ready) {      // (the forward has them from its embed launch: lo / hi cleared with the other per-forward words)
         (void)hipMemsetAsync(lo, 0, (size_t)R * sizeof(int), st);
         (void)hipMemsetAsync(hi, 0, (size_t)R * sizeof(int), st);
         hipLaunchKernelGGL(k_seg_bounds, dim3((N + 255) / 256), dim3(256), 0, st, N, R, roa, lo, hi, err_flag);
     }
     hipLaunchKernelGGL(k_pool_logits, dim3((N + 7) / 8), dim3(256), 0, st, W, mw.sam, N, q, p, a_tmp);
-    hipLaunchKernelGGL(k_pool_reduce, dim3(R), dim3(64), 0, st, W, mw, n_out, R, q, p, a_tmp, roa, lo, hi, qr_out, pr_out, z_out, err_flag);
+    hipLaunchKernelGGL(k_pool_reduce, dim3(R), dim3(64), 0, st, W, mw, n_out, R, q, p, a_tmp, roa, lo, hi, qr_out, pr_out, z_out, err_flag, sc, only_flagged ? 1 : 0);
 }
 
 

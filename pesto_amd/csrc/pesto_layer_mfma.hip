@@ -77,6 +77,20 @@ __device__ __forceinline__ void sat_probe(float& acc, float x) { acc = __builtin
 __device__ __forceinline__ void sat_flush(float acc, int* __restrict__ flags) {
     if (acc != acc) atomicOr(flags, 4);
 }
+// The guard is kept PER STRUCTURE (SatCtx, pesto_kernels.h): a lane's probes cover the MFMA columns of one centre at a time, and NaN /
+// inf never cross from one structure of a launch to another (neighbour gathers stay inside a structure; MFMA columns - and, with edges
+// as rows, rows - are independent). A probe that ended as NaN sets bit 2 of the launch's flags word AND of the word of the centre's
+// structure; the pool kernel turns only that structure's logits into NaN and PESTO_PRECISION_AUTO repeats only that structure in fp32,
+// so a structure's bits do not depend on its batch mates. row = index into the state arrays (0 = sink: no structure, never flagged).
+// The kernels take only the flags word's address, as before the guard was per structure (their register budget is exhausted: three more
+// kernel arguments spilled in the nn = 64 instantiations); the rare path reads the SatCtx the forward's first launch left behind the word.
+__device__ __forceinline__ void sat_flush_at(float acc, int* __restrict__ flags, int row) {
+    if (acc != acc && row > 0) {
+        const SatCtx sc = *reinterpret_cast<const SatCtx*>(flags + SATCTX_OFFSET_INTS);
+        atomicOr(flags, 4);
+        atomicOr(sc.sflags + (sc.seg_of_atom ? sc.seg_of_atom[row - 1] : sc.frame_n ? (row - 1) / sc.frame_n : 0), 4);
+    }
+}
 __device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast<const f16x8*>(p); }
 #ifdef PESTO_ABL_NOWL   // ablation: the low weight fragments are not read from LDS (results wrong): -1/3 of the LDS weight traffic
 #define PESTO_WL(fr) ld8h(fr) 
@@ -124,6 +138,15 @@ __device__ __forceinline__ f32x4 elu4s(f32x4 t) {
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// Centre records are stored FINITE (v_med3 maps NaN / +-inf to +-3e38): in an nn = 8 tile two centres share one centre MFMA, each seeing
+// the other's record against a zero B column - 0 x NaN would carry an overflowed structure's NaN into the first / last atom of its
+// neighbour in the launch. The overflow itself has been flagged by the probes in front of the store (per structure), the structure is
+// computed again in fp32; what the split kernels go on computing for it no longer matters, but it must stay inside it.
+__device__ __forceinline__ void st4_finite(float* p, f32x4 v) {
+    constexpr float M = 3.0e38f;
+    st4(p, f32x4{__builtin_amdgcn_fmed3f(v[0], -M, M), __builtin_amdgcn_fmed3f(v[1], -M, M), __builtin_amdgcn_fmed3f(v[2], -M, M),
+                 __builtin_amdgcn_fmed3f(v[3], -M, M)});
+}
 
 // acc[m] += W[m-block][fb-block] * x for the four k-steps r of block fb; frag table [m][fb][lane][r] in `wf`
 template <int NFB>
@@ -425,7 +448,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
                 st4(dst + 4 * g, st[0]); st4(dst + 16 + 4 * g, st[1]);
             }
         }
-        if (!do_prep) continue;
+        if (!do_prep) { if (valid) sat_flush_at(sat, flags, i); sat = 0.0f; continue; }
         // exchange the tile state between the four roles
         st4(xs + (2 * role) * 256 + lane * 4, st[0]);
         st4(xs + (2 * role + 1) * 256 + lane * 4, st[1]);
@@ -465,7 +488,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
             if (valid) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);
+                    if (ob < 8) st4_finite(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);
                     else st4(nb + (ob + j - 8) * 16 + 4 * g, a[j]);                   // A_j[16 fb + 4g + r]
                 }
             }
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) st4(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
+                    for (int c = 0; c < 3; ++c) st4_finite(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
             }
         }
         if (role == 3) {   // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12                        (:119)
@@ -512,8 +535,9 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
             sat_probe(sat, qq[0][0]);
             if (valid) st4(cen + 512 + 4 * g, qq[0]);
         }
+        if (valid) sat_flush_at(sat, flags, i);      // (this lane's probes cover MFMA column e = atom i of the tile)
+        sat = 0.0f;
     }
-    sat_flush(sat, flags);
 }
 
 // ---- cross-lane reductions on the VALU (DPP) instead of ds_bpermute round trips through the LDS crossbar
@@ -1441,7 +1465,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     const int chunk = (n_work + 7) >> 3;
     const int w_end = min(n_work, (xcd + 1) * chunk);
     PHASE_DECL();
-    float sat = 0.0f;       // range guard of the f16-split path (sat_probe)
+    // range guard of the f16-split path (sat_probe), flushed per centre (sat_flush_at). sat_b: the second centre of a two-centre item
+    // whose centres are different tiles (nn = 16 / 32); for nn = 8 the two centres of a tile are different lanes
+    float sat = 0.0f, sat_b = 0.0f;
+    constexpr bool SAT2 = F16 && FIN && !M32 && A == 2 && NN >= 16;
     int fin_iter = 0;       // finish phases done (FIN)
     // the trip count is the same for every wave of a workgroup (FIN: workgroup barriers inside); a wave without a work item idles
     // An iteration hands every wave SUBS items. Full iterations: consecutive blocks of WPB items per wave-slot (neighbouring centres
@@ -1485,6 +1512,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             PHASE_INIT();
             TRACE32(20);
             edge_item32<NN, TI / 2>(ws, sm.w, zrow, sub, lane, c0, N1, make_rsrc(rec_nb), make_rsrc(rec_cen), make_rsrc(p_state), inv_sdk, sat, tr_n);
+            // (developer variant: a lane's probes cover every centre of the item - all of them are flagged)
+#pragma unroll
+            for (int a = 0; a < A; ++a) if (c0 + a < N1) sat_flush_at(sat, flags, c0 + a);
+            sat = 0.0f;
             PHASE_MARK(1);
             if (!FIN) {      // unfused variant: the Z rows of the item's centres go to memory, the node kernel applies the output MLPs
 #pragma unroll
@@ -1623,6 +1654,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     L1Raw raw = l1_issue<NN>(0, 0, lane, tcc, ws, p_state);
 #pragma unroll 1
                     for (int t = 0; t < TI; ++t) {
+                        if (SAT2 && t == TI / 2) { const float tmp = sat; sat = sat_b; sat_b = tmp; }      // the second centre's tiles start
                         L1Head hd = l1_head<NN>(raw, t, lane, tcc, ws);
                         __builtin_amdgcn_sched_barrier(0);
                         if (t < TI - 1) {
@@ -1638,6 +1670,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         keys_of_tile(t, h1);
                         __builtin_amdgcn_s_setprio(0);
                     }
+                    if (SAT2) { const float tmp = sat; sat = sat_b; sat_b = tmp; }      // sat: first centre again, sat_b: second
                 }
             }
         }
@@ -1881,6 +1914,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             }
             PHASE_MARK(5);
             if ((t + 1) % TPC != 0) continue;   // centre continues in the next tile
+            if (F16) {   // range guard of the centre(s) that end here: this lane's probes of both passes were columns (edges) of that centre
+                if (sat != sat) {      // (rare: everything it needs is derived inside the branch)
+                    const int rowc = c0 + (NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN);
+                    if (rowc < N1) sat_flush_at(sat, flags, rowc);
+                }
+                // (unfused developer kernels hold more than two centres per item: their probes stay sticky within the item, which can
+                // only flag too many of the item's centres, never too few)
+                if (FIN) { sat = sat_b; sat_b = 0.0f; }
+            }
             // ---- centre(s) complete: reduce the per-lane partial sums across lane groups, stage in LDS
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -1962,6 +2004,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             __builtin_amdgcn_wave_barrier();
             PHASE_MARK(6);
         }
+        if (F16 && !FIN) sat = 0.0f;
         }   // !M32
       }   // work item
       }   // sub
@@ -2184,11 +2227,13 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         sat_probe(sat, a[0][0]);
                         if (valid) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) st4(cen + (4 * half + j) * 64 + (role - 1) * 16 + 4 * fg, a[j]);
+                            for (int j = 0; j < 4; ++j) st4_finite(cen + (4 * half + j) * 64 + (role - 1) * 16 + 4 * fg, a[j]);
                         }
                     }
                 }
             }
+            if (valid) sat_flush_at(sat, flags, ci);      // (the probes of this phase are MFMA column fe = centre ci)
+            sat = 0.0f;
             __builtin_amdgcn_s_setprio(0);
             PHASE_MARK(11);
         } else {       // waves without a finish role: the [U | A] blocks 4j .. 4j+3 of every tile (U = blocks 0..7 carries b1, A = 8..15)
@@ -2233,12 +2278,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][1], xnh[kgp], a[j]);
                     }
                     sat_probe(sat, a[0][0]);
+                    if (valid) sat_flush_at(sat, flags, ci);
+                    sat = 0.0f;
                     if (valid) {
                         float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
                         float* nb = rec_nb_out + (size_t)ABL_ST(ci) * REC_A;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
+                            if (ob < 8) st4_finite(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
                             else st4(nb + (ob + j - 8) * 16 + 4 * fg, a[j]);                   // A_j[16 fb + 4g + r]
                         }
                     }
@@ -2370,7 +2417,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         sat_probe(sat, a[0][0]);
                         if (valid) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) st4(cen + (4 * half + j) * 64 + (role - 1) * 16 + 4 * fg, a[j]);
+                            for (int j = 0; j < 4; ++j) st4_finite(cen + (4 * half + j) * 64 + (role - 1) * 16 + 4 * fg, a[j]);
                         }
                     }
                 }
@@ -2424,7 +2471,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         float* nb = rec_nb_out + (size_t)ABL_ST(ci) * REC_A;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (ob < 8) st4(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
+                            if (ob < 8) st4_finite(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
                             else st4(nb + (ob + j - 8) * 16 + 4 * fg, a[j]);                   // A_j[16 fb + 4g + r]
                         }
                     }
@@ -2457,11 +2504,13 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 }
             }
 #undef PESTO_FIN_MFMA
+            if (valid) sat_flush_at(sat, flags, ci);      // (the probes of a node wave are MFMA column fe = centre ci)
+            sat = 0.0f;
         }
         ++fin_iter;
       }
     }
-    if (F16) sat_flush(sat, flags);
+    if (F16) sat_flush(sat + sat_b, flags);      // (nothing is left here: every probe has been flushed with its centre)
     PHASE_FLUSH();
     TRACE32(51);
 }

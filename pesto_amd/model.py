@@ -13,8 +13,13 @@ says where the caller's tensors live: CUDA(ROCm) tensors are consumed in place o
 CPU tensors / numpy arrays are staged through the library's own buffers.
 
 ``precision`` (no reference counterpart - torch computes in fp32): "auto" (default) runs the state-update GEMMs as f16 hi/lo
-split MFMA and repeats a forward on the exact fp32 kernels when an activation left the f16 range; "f16_split" never
-repeats (such a forward raises / returns NaN); "fp32" always uses the exact fp32 MFMA kernels (enum pesto_precision).
+split MFMA and computes every STRUCTURE in which an activation left the f16 range again on the exact fp32 kernels (the other
+structures of the launch keep their logits: results do not depend on the grouping); "f16_split" never repeats (such a structure
+raises / returns NaN); "fp32" always uses the exact fp32 MFMA kernels (enum pesto_precision).
+``async_auto`` (default False): with ROCm tensors and precision "auto", ``model(...)`` returns once the launch's range / input check
+has been read back (one 4-byte copy + a stream synchronisation), so ``z`` is final - what a drop-in caller that goes on with
+``torch.sigmoid(z)`` needs. True makes the call fully asynchronous: the check is made by the NEXT call on the model (or
+``synchronize()``), which may write the fp32 repeat into the same ``z``; until then an overflowed structure holds NaN.
 """
 import ctypes
 
@@ -31,14 +36,14 @@ def _is_torch(x):
 
 
 class Model:
-    def __init__(self, config, device=None, validate=True, precision="auto"):
+    def __init__(self, config, device=None, validate=True, precision="auto", async_auto=False):
         self.config = normalise(config)
         self.precision = str(precision).lower()
+        self.async_auto = bool(async_auto)
         self._cc = _lib.make_c_config(self.config, self.precision)
         self._debug = (0, 0)        # pesto_debug_select(layer_kernels, knn_brute_force): test hook
         self._edge_mode = 0         # pesto_debug_edge_mode: test hook
-        self._last_device_call = None           # tensors of the last asynchronous device call (kept alive for its deferred check)
-        self._first_device_call_checked = False
+        self._last_device_call = None           # async_auto: tensors of the last device call (kept alive for its deferred check)
         self._blob = None
         self._handle = None
         self._gpu = 0
@@ -64,6 +69,17 @@ class Model:
         self._cc.precision = code
         if self._handle is not None:
             _lib.check(_lib.load().pesto_set_precision(self._handle, code))
+        return self
+
+    def set_async_auto(self, enabled=True):
+        """pesto_set_async_auto: precision "auto" with ROCm tensors returns without synchronising; the launch is checked by the next
+        call on the model (see the module docstring). Callers that consume z through postprocess() / a later model call, like
+        apply.apply_model, switch this on."""
+        self.async_auto = bool(enabled)
+        if self._handle is not None:
+            _lib.check(_lib.load().pesto_set_async_auto(self._handle, 1 if self.async_auto else 0))
+        if not self.async_auto:
+            self._last_device_call = None
         return self
 
     def status(self):
@@ -136,7 +152,6 @@ class Model:
             _lib.load().pesto_destroy(self._handle)
             self._handle = None
         self._last_device_call = None
-        self._first_device_call_checked = False
 
     def __del__(self):
         try:
@@ -157,6 +172,8 @@ class Model:
                 _lib.check(lib.pesto_debug_select(h, *self._debug))
             if self._edge_mode:
                 _lib.check(lib.pesto_debug_edge_mode(h, self._edge_mode))
+            if self.async_auto:
+                _lib.check(lib.pesto_set_async_auto(h, 1))
         return self._handle
 
     @property
@@ -230,14 +247,10 @@ class Model:
             stream = torch.cuda.current_stream(X.device).cuda_stream
             _lib.check(call(N, k, Xc.data_ptr(), ids.data_ptr(), _lib.IDS_INT64 if ids.dtype == torch.int64 else _lib.IDS_INT32,
                             qc.data_ptr(), roa.data_ptr(), z.data_ptr(), _lib.PTR_DEVICE, stream))
-            # precision "auto" is asynchronous here: the range / input check of this launch is made by the NEXT call on the handle
-            # (or synchronize()), which may repeat it on the fp32 kernels into the same z - its buffers stay referenced until then.
-            # The first device call of a handle is checked at once, so a model whose states leave the f16 range on ordinary inputs
-            # (the reference's trained i_v3_1) switches to the exact kernels before any result is consumed.
-            self._last_device_call = (Xc, ids, qc, roa, z)
-            if not self._first_device_call_checked:
-                self._first_device_call_checked = True
-                self.synchronize()
+            # precision "auto": checked before the call returned (z is final). async_auto: the check is made by the NEXT call on the handle
+            # (or synchronize()), which may repeat flagged structures on the fp32 kernels into the same z - the launch's buffers stay
+            # referenced until then.
+            self._last_device_call = (Xc, ids, qc, roa, z) if self.async_auto else None
             return z
         # host path: CPU torch tensors or numpy arrays
         as_torch = _is_torch(X)
@@ -336,7 +349,11 @@ class Model:
         for b, (X, ids, q0, M) in enumerate(structures):
             roa, R = mask_to_segments(M) if self.validate else (np.asarray(M.detach().cpu().numpy() if _is_torch(M) else M).argmax(1).astype(np.int32), int(M.shape[1]))
             Xn = np.ascontiguousarray(X.detach().cpu().numpy() if _is_torch(X) else X, dtype=np.float32)
-            idn = np.ascontiguousarray((ids.detach().cpu().numpy() if _is_torch(ids) else np.asarray(ids)).astype(id_dtype, copy=False))
+            idr = ids.detach().cpu().numpy() if _is_torch(ids) else np.asarray(ids)
+            if id_dtype is np.uint16 and idr.size and (int(idr.min()) < 0 or int(idr.max()) > 65535):
+                # narrowing would wrap an invalid id into a valid one: hand the table over as it is (the library rejects it)
+                raise ValueError(f"structure {b}: ids_topk has entries outside [0, N)")
+            idn = np.ascontiguousarray(idr.astype(id_dtype, copy=False))
             qn = np.ascontiguousarray(q0.detach().cpu().numpy() if _is_torch(q0) else q0, dtype=np.float32)
             roa = np.ascontiguousarray(roa, dtype=np.int32)
             N = Xn.shape[0]
@@ -347,7 +364,7 @@ class Model:
             if use_idx:      # one-hot rows -> block-local byte indices (exactly one 1 per block, else fall back to the dense form)
                 bounds = list(offs) + [n0]
                 cols = [qn[:, bounds[c]:bounds[c + 1]] for c in range(len(offs))]
-                if all(np.array_equal(c.sum(1), np.ones(N, np.float32)) and np.array_equal(c.max(1), np.ones(N, np.float32)) for c in cols):
+                if all(bool(((c == 0) | (c == 1)).all()) and bool((np.count_nonzero(c, 1) == 1).all()) for c in cols):
                     qi = np.ascontiguousarray(np.stack([c.argmax(1) for c in cols], 1).astype(np.uint8))
                 else:
                     use_idx = False
@@ -420,6 +437,7 @@ class Model:
             _lib.check(lib.pesto_forward_frames(h, N, R, ids.shape[1], F, Xc.data_ptr(), fs, as_, ids.data_ptr(),
                                                 _lib.IDS_INT64 if ids.dtype == torch.int64 else _lib.IDS_INT32, qc.data_ptr(),
                                                 roa.data_ptr(), z.data_ptr(), frames_per_launch, _lib.PTR_DEVICE, stream))
+            self._last_device_call = (Xc, ids, qc, roa, z) if self.async_auto else None      # (as in forward_segments)
             return z
         as_torch = _is_torch(X_frames)
         Xn = np.asarray(X_frames.detach().numpy() if as_torch else X_frames)

@@ -723,8 +723,9 @@ def test_config3_i_v3_0_at_n3000():
 
 def test_trained_i_v3_1_range_guard():
     """The reference's TRAINED i_v3_1 drives its states to 4e5, beyond the f16 range of the split-MFMA kernels. "auto" must notice
-    and repeat the forward on the exact fp32 kernels (finite, within the reference's own fp32-vs-fp64 noise); "f16_split" must fail
-    loudly (error on the synchronising path, all-NaN logits on the asynchronous one) - never a plausible wrong number."""
+    and compute the structure again on the exact fp32 kernels (finite, within the reference's own fp32-vs-fp64 noise) - before the
+    call returns, also with device tensors; with async_auto the check is deferred to the next call on the handle. "f16_split" must
+    fail loudly (error on the synchronising path, NaN logits on the asynchronous one) - never a plausible wrong number."""
     import torch
     from pesto_amd import Model
     from pesto_amd._lib import ERR_RANGE, PestoError
@@ -741,38 +742,47 @@ def test_trained_i_v3_1_range_guard():
     m.set_precision("fp32")
     z_fp32 = m.forward_segments(*args)
     assert np.array_equal(z_fp32, z_auto) and m.status()["n_fp32_rerun"] == 1
-    # after one overflow "auto" runs the exact kernels first (no second repeat) until the precision is set again
+    # no history: "auto" tries the split kernels on every call (a structure's bits must not depend on what the handle saw before)
     assert np.array_equal(m.set_precision("auto").forward_segments(*args), z_auto) and m.status()["n_fp32_rerun"] == 2
-    assert np.array_equal(m.forward_segments(*args), z_auto) and m.status()["n_fp32_rerun"] == 2
-    # device tensors: "auto" is asynchronous - the first device call of a model is checked at once (and repeated here), later calls
-    # are checked by the next call on the handle / synchronize(): until then an overflowed launch holds NaN, afterwards the fp32 result
+    assert np.array_equal(m.forward_segments(*args), z_auto) and m.status()["n_fp32_rerun"] == 3
+    # device tensors: checked (and repeated) before the call returns - a drop-in caller can go on with torch.sigmoid(z)
     dev = torch.device("cuda:0")
-    m.set_precision("auto").to(dev)
+    m.to(dev)
     targs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in args[:4]]
     z_dev = m.forward_segments(*targs, args[4])
-    assert np.array_equal(z_dev.cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 3
-    m.set_precision("auto")                                        # forget the overflow: the next launch runs the split kernels again
+    assert np.array_equal(z_dev.cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 4
+    zf_dev = m.forward_frames_segments(torch.stack([targs[0], targs[0]]), *targs[1:4], args[4])     # the frames path too
+    assert np.array_equal(zf_dev[0].cpu().numpy(), z_auto) and np.array_equal(zf_dev[1].cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 6
+    # async_auto: the launch returns at once; until the next call on the handle an overflowed structure holds NaN, afterwards the fp32 result
+    m.set_async_auto(True)
     z_late = m.forward_segments(*targs, args[4])
     torch.cuda.synchronize()
     assert torch.isnan(z_late).all()                               # loud until the deferred check has run
     m.synchronize()
-    assert np.array_equal(z_late.cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 4
+    assert np.array_equal(z_late.cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 7
+    zf_late = m.forward_frames_segments(torch.stack([targs[0], targs[0]]), *targs[1:4], args[4])
+    m.synchronize()
+    assert np.array_equal(zf_late[1].cpu().numpy(), z_auto) and m.status()["n_fp32_rerun"] == 9
+    m.set_async_auto(False)
     # f16_split: loud failure
     m.set_precision("f16_split")
     with pytest.raises(PestoError) as e:
         m.forward_segments(*args)
     assert e.value.code == ERR_RANGE
-    z_nan = m.forward_segments(*targs, args[4])                    # asynchronous and unchecked: every logit NaN
+    z_nan = m.forward_segments(*targs, args[4])                    # asynchronous and unchecked: every logit of the structure NaN
     assert torch.isnan(z_nan).all()
     # the handle is not poisoned: a well-behaved model state afterwards
     m.set_precision("auto")
     assert np.array_equal(m.to("cpu").forward_segments(*args), z_auto)
-    # bad inputs on the asynchronous path are reported by the next call
+    # bad inputs: reported by the call itself; on the asynchronous path by the next call
     m40d = _model("i_v4_0", "mfma").to(dev)
     g40 = golden("fwd_i_v4_0_2CUA")
     t40 = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (g40["X"], g40["ids_topk"].astype(np.int64), onehot(g40["q_idx"], 30), g40["res_of_atom"])]
     z_ok = m40d.forward_segments(*t40, g40["z"].shape[0])
     bad_ids = t40[1].clone(); bad_ids[5, 3] = 10 ** 6
+    with pytest.raises(PestoError):
+        m40d.forward_segments(t40[0], bad_ids, t40[2], t40[3], g40["z"].shape[0])
+    m40d.set_async_auto(True)
     z_bad = m40d.forward_segments(t40[0], bad_ids, t40[2], t40[3], g40["z"].shape[0])             # returns at once
     with pytest.raises(PestoError):
         m40d.synchronize()
@@ -784,11 +794,81 @@ def test_trained_i_v3_1_range_guard():
     assert m40.status() == {"precision": "auto", "n_forward": 1, "n_fp32_rerun": 0}
 
 
+def _exploded(st, factor=3.0e4):
+    """the same structure with coordinates scaled so that its distances (1e5) leave the f16 range inside the first edge layer"""
+    return (st[0] * np.float32(factor),) + tuple(st[1:])
+
+
+def test_range_guard_is_per_structure():
+    """SURVEY 8e acceptance under the DEFAULT precision: a structure's bits do not depend on its batch mates, also when one of them
+    leaves the f16 range. A launch of [clean, overflowing, clean, overflowing, clean (N < 64)] through the trained i_v4_0: only the two
+    flagged members are computed again on the fp32 kernels (n_fp32_rerun counts structures); every member equals its own call bit for
+    bit - the clean ones on the split kernels, the flagged ones on the exact kernels - on the synchronous batch call, the pipelined
+    submit / wait path, the collated device call with structure offsets, and as trajectory frames (the guard is per frame)."""
+    import torch
+    from pesto_amd.topology import collate_batch_features, mask_to_segments
+    m = _model("i_v4_0", "mfma")
+    parts = _split_batch_fixture(golden("edge_batch2"))           # 300 + 40 atoms
+    g = golden("fwd_i_v4_0_2CUA")
+    roa = g["res_of_atom"]
+    Mc = np.zeros((roa.size, int(roa.max()) + 1), np.float32); Mc[np.arange(roa.size), roa] = 1
+    big = (g["X"], g["ids_topk"].astype(np.int32) - 1, onehot(g["q_idx"], 30), Mc)      # 955 atoms
+    structs = [parts[0], _exploded(big), big, _exploded(parts[0]), parts[1]]
+    flagged = [False, True, False, True, False]
+    solo = []
+    for st, f in zip(structs, flagged):
+        n0 = m.status()["n_fp32_rerun"]
+        solo.append(m.forward_batch([st], independent=True)[0])
+        assert m.status()["n_fp32_rerun"] == n0 + (1 if f else 0)
+        assert np.isfinite(solo[-1]).all()
+    m.set_precision("fp32")
+    for st, f, z in zip(structs, flagged, solo):
+        if f:
+            assert np.array_equal(m.forward_batch([st], independent=True)[0], z)      # a flagged structure = its exact-kernel result
+    m.set_precision("f16_split")
+    for st, f, z in zip(structs, flagged, solo):
+        if not f:
+            assert np.array_equal(m.forward_batch([st], independent=True)[0], z)      # a clean one = its split-kernel result
+    m.set_precision("auto")
+    n0 = m.status()["n_fp32_rerun"]
+    zb = m.forward_batch(structs, independent=True)
+    assert m.status()["n_fp32_rerun"] == n0 + 2
+    zp = m.forward_batch_wait(m.forward_batch_submit(structs, independent=True))
+    assert m.status()["n_fp32_rerun"] == n0 + 4
+    for j in range(len(structs)):
+        assert np.array_equal(zb[j], solo[j]) and np.array_equal(zp[j], solo[j]), j
+    # f16_split: only the flagged members are NaN on the asynchronous device path; the others keep their logits
+    dev = torch.device("cuda:0")
+    Xc, idc, qc, Mcol = collate_batch_features([list(s) for s in structs])
+    roa_c, R_c = mask_to_segments(Mcol)
+    sizes = [s[0].shape[0] for s in structs]
+    roffs = np.cumsum([0] + [s[3].shape[1] for s in structs])
+    md = _model("i_v4_0", "mfma").to(dev)
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (Xc, idc.astype(np.int64), qc, roa_c)]
+    zd = md.forward_segments(*t, R_c, sizes=sizes).cpu().numpy()            # "auto", device pointers: final at return
+    for j in range(len(structs)):
+        assert np.array_equal(zd[roffs[j]:roffs[j + 1]], solo[j]), j
+    assert md.status()["n_fp32_rerun"] == 2
+    md.set_precision("f16_split")
+    zs = md.forward_segments(*t, R_c, sizes=sizes).cpu().numpy()
+    for j, f in enumerate(flagged):
+        blk = zs[roffs[j]:roffs[j + 1]]
+        assert np.isnan(blk).all() if f else np.array_equal(blk, solo[j]), j
+    # trajectory frames: frame 1 of 3 exploded - the guard and the repeat are per frame
+    md.set_precision("auto")
+    n0 = md.status()["n_fp32_rerun"]
+    Xf = np.stack([big[0], big[0] * np.float32(3.0e4), big[0]])
+    zf = md.forward_frames_segments(torch.from_numpy(Xf).to(dev), torch.from_numpy(g["ids_topk"].astype(np.int64)).to(dev),
+                                    torch.from_numpy(big[2]).to(dev), torch.from_numpy(roa.astype(np.int32)).to(dev), int(roa.max()) + 1).cpu().numpy()
+    assert md.status()["n_fp32_rerun"] == n0 + 1
+    assert np.array_equal(zf[0], solo[2]) and np.array_equal(zf[2], solo[2]) and np.array_equal(zf[1], solo[1])
+
+
 def test_range_guard_on_the_pipelined_bulk_path():
     """The TRAINED i_v3_1 (states beyond the f16 range) through pesto_forward_batch_submit / _wait with two launches in flight: under
-    "auto" each flagged slot is repeated on the exact fp32 kernels from its own staged inputs when it is waited for (the second slot
-    was queued on the split kernels before the first one was looked at), later submits run the exact kernels first; "f16_split"
-    reports PESTO_ERR_RANGE at the wait. Results = the synchronous "fp32" forward, bit for bit."""
+    "auto" the flagged structures of a slot are computed again on the exact fp32 kernels from the slot's own staged inputs when it is
+    waited for (the second slot was queued on the split kernels before the first one was looked at, and has used the shared workspace
+    in between); "f16_split" reports PESTO_ERR_RANGE at the wait. Results = the synchronous "fp32" forward, bit for bit."""
     from pesto_amd._lib import ERR_RANGE, PestoError
     g = golden("fwd_i_v3_0_2CUA")
     roa = g["res_of_atom"]
@@ -807,9 +887,9 @@ def test_range_guard_on_the_pipelined_bulk_path():
     z1 = m.forward_batch_wait(t1)
     z2 = m.forward_batch_wait(t2)
     assert np.array_equal(z1[0], z_fp32) and np.array_equal(z2[0], z_fp32) and np.array_equal(z2[1], z_fp32)
-    assert m.status()["n_fp32_rerun"] == n0 + 2
-    z3 = m.forward_batch_wait(m.forward_batch_submit([st]))          # the handle runs the exact kernels first now: no repeat
-    assert np.array_equal(z3[0], z_fp32) and m.status()["n_fp32_rerun"] == n0 + 2
+    assert m.status()["n_fp32_rerun"] == n0 + 3                       # structures, not launches
+    z3 = m.forward_batch_wait(m.forward_batch_submit([st]))          # no history: tried on the split kernels again, repeated again
+    assert np.array_equal(z3[0], z_fp32) and m.status()["n_fp32_rerun"] == n0 + 4
     m.set_precision("f16_split")
     t = m.forward_batch_submit([st])
     with pytest.raises(PestoError) as e:
@@ -970,10 +1050,14 @@ def test_mask_to_segments_kernel_and_the_reference_signature():
             rows = np.where(roa == r)[0]
             Mb[rows] = 0.0
             Mb[rows, (r + 1) % R] = 1.0
+        with pytest.raises(PestoError):                       # precision "auto": the call checks its inputs before it returns
+            m(*args, torch.from_numpy(Mb).to(dev))
+        m.set_async_auto(True)
         z_bad = m(*args, torch.from_numpy(Mb).to(dev))        # asynchronous: NaN logits now, the error at the next call on the handle
         with pytest.raises(PestoError):
             m.synchronize()
         assert torch.isnan(z_bad).all()
+        m.set_async_auto(False)
     # host-pointer form reports the bad row itself
     lib = _lib.load()
     Mb = M.copy(); Mb[11] = 0.0
