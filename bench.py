@@ -75,6 +75,33 @@ def layer_gather_bytes_per_atom(nn):
     return 1024.0 + 532.0 * nn
 
 
+def per_nn_table(config, kern, n1, traffic_file):
+    """{nn: launch time by HIP events, def-A fraction by events and by the committed rocprofv3 trace, HBM-side traffic per launch,
+    traffic / compulsory bytes (def. B)} for every layer kernel of the forward; the profile-derived entries are None unless the
+    committed profile carries the source hash of this build."""
+    table, frac_rp = {}, {}
+    for nn in sorted({l["nn"] for l in config["sum"]}):
+        k = kern.get(f"edge_nn{nn}")
+        if not k:
+            continue
+        b_a = layer_gather_bytes_per_atom(nn) * n1
+        row = {"avg_launch_ms": k["avg_launch_ms"], "launches_per_forward": k["launches_per_forward"],
+               "frac_def_A": b_a / (k["avg_launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+               "rocprof_avg_launch_ms": None, "frac_def_A_rocprof": None, "traffic": None, "traffic_over_compulsory": None}
+        if traffic_file:
+            hit = [v for kk, v in traffic_file["kernels"].items() if f"k_edge<{nn}," in kk]
+            if hit:
+                row["traffic"] = 2.0 * hit[0]["fetch_bytes_per_dispatch_raw"] + hit[0]["write_bytes_per_dispatch"]
+                row["traffic_over_compulsory"] = row["traffic"] / ((1024.0 + 4.0 * nn) * n1)
+            tr = [v for kk, v in traffic_file.get("rocprof_kernel_trace", {}).get("kernels", {}).items() if f"k_edge<{nn}," in kk]
+            if tr:
+                row["rocprof_avg_launch_ms"] = tr[0]["avg_ns"] * 1e-6
+                row["frac_def_A_rocprof"] = b_a / (tr[0]["avg_ns"] * 1e-9) / 1e9 / PEAK_HBM_GBS
+                frac_rp[nn] = row["frac_def_A_rocprof"]
+        table[str(nn)] = row
+    return table, frac_rp
+
+
 def make_batch(n_atoms, batch, seed0, n0, order="random"):
     from pesto_amd.topology import collate_batch_features, mask_to_segments, synthetic_structure
     items = [list(synthetic_structure(n_atoms, seed0 + b, n0=n0, order=order)) for b in range(batch)]
@@ -152,6 +179,7 @@ def cpu_baseline(config, sd, n_atoms, budget_s, config_key):
                                           "sample": f"{n8} x the same structure", "speedup_of_the_best_team_over_these": t8 / t}
             out["reference_equivalent"] = {"rho": rho, "threads": min(thr, all_threads), "seconds_per_structure": rho * t8,
                                            "structures_per_s": 1.0 / (rho * t8),
+                                           "estimate": True, "rho_machine": "build container (no GPU), not this host",
                                            "provenance": f"rho = reference PyTorch CPU time / C-oracle time on the same {thr} threads of the "
                                                          f"build container (torch {r['torch']}), profiles/r02_cpu_rho.json, times the port's "
                                                          f"time at {min(thr, all_threads)} threads on THIS host; the reference itself cannot "
@@ -193,8 +221,7 @@ def config4_structures(n_structures, model=None):
         ids = model.knn_collate(np.concatenate([it[0] for it in items]), sizes)          # [sum N, 64], 1-based batch-global
         off = 0
         for it, n in zip(items, sizes):
-            it[1] = (ids[off:off + n] - (off + 1)).astype(np.int32)                      # 0-based within the structure (N >= 64: no padding);
-                                                                                          # int32 halves the H2D volume of the tables
+            it[1] = (ids[off:off + n] - (off + 1)).astype(np.int32)                      # 0-based within the structure (N >= 64: no padding)
             off += n
         if refs is not None:
             # 21 rows of these chains hold two neighbours at exactly the same fp32 distance; torch.topk put them the other way round
@@ -203,6 +230,13 @@ def config4_structures(n_structures, model=None):
             for c, r, col, v in g["tie_patches"]:
                 for i in range(int(c), n_structures, n_chains):
                     items[i][1][r, col] = v
+    if model is not None and model.config["em"]["N0"] == 30:
+        # the compact per-structure forms of forward_batch_submit, as a loader would hand them over (encode_features' argmax, the residue
+        # column per atom, uint16 neighbour ids): the Python layer then touches no array element and the library packs bytes
+        for it in items:
+            it[1] = it[1].astype(np.uint16) if it[0].shape[0] <= 65536 else it[1]
+            it[2] = np.ascontiguousarray(it[2].argmax(1).astype(np.uint8)[:, None])
+            it[3] = np.ascontiguousarray(it[3].argmax(1).astype(np.int32))
     return [tuple(it) for it in items], sizes, refs
 
 
@@ -222,11 +256,14 @@ def config4_leg(model, dist, backend, dev, n_structures, reps, max_atoms):
         torch.cuda.synchronize()
 
     gathered = sharding.forward_sharded(model, structures, n_out, max_atoms=max_atoms)       # warm-up (workspace growth, RCCL setup)
-    times = []
+    times, per_rank = [], []
     for _ in range(reps):
         barrier()
         t0 = time.perf_counter()
-        gathered = sharding.forward_sharded(model, structures, n_out, max_atoms=max_atoms)
+        c0 = time.process_time()
+        tm = {}
+        gathered = sharding.forward_sharded(model, structures, n_out, max_atoms=max_atoms, timings=tm)
+        cpu_s = time.process_time() - c0
         barrier()
         el = time.perf_counter() - t0
         if dist is not None:
@@ -234,6 +271,7 @@ def config4_leg(model, dist, backend, dev, n_structures, reps, max_atoms):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         times.append(el)
+        per_rank.append(gather_rank_stats(dist, backend, dev, [tm["local_s"], tm["gather_s"], cpu_s, tm["structures"], tm["atoms"]]))
     if rank != 0:
         return None
     # world-1 run of the same list on this rank; every structure must come back with the same bits (PESTO_BATCH_INDEPENDENT)
@@ -253,7 +291,26 @@ def config4_leg(model, dist, backend, dev, n_structures, reps, max_atoms):
                         f"({backend if world > 1 else 'no collective at world 1'})",
             "structures": len(structures), "structures_per_rank": len(structures) // world, "value": len(structures) / t_med, "unit": "structures/s",
             "scaling": "weak (the list grows with the world size: a fixed number of structures per rank)",
-            "seconds_per_pass_median": t_med, "passes": reps, "bitwise_equal_to_world1": bool(ok), "parity_max_abs_vs_reference": parity}
+            "seconds_per_pass_median": t_med, "passes": reps, "bitwise_equal_to_world1": bool(ok), "parity_max_abs_vs_reference": parity,
+            # per rank (median over the passes): seconds in its own launches, seconds waiting in / doing the result gather, CPU seconds of
+            # the rank's process (packing, submit / wait, gather), its share of the list - a straggler or a starved host shows here
+            "per_rank": [{"rank": r, "local_s": float(np.median([p[r][0] for p in per_rank])), "gather_s": float(np.median([p[r][1] for p in per_rank])),
+                          "host_cpu_s": float(np.median([p[r][2] for p in per_rank])), "structures": int(per_rank[0][r][3]), "atoms": int(per_rank[0][r][4]),
+                          "structures_per_s": float(per_rank[0][r][3] / np.median([p[r][0] for p in per_rank]))} for r in range(world)],
+            "rank_local_s_max_over_min": float(max(np.median([p[r][0] for p in per_rank]) for r in range(world)) /
+                                               max(1e-12, min(np.median([p[r][0] for p in per_rank]) for r in range(world)))),
+            "host_cpu_s_per_structure": float(np.median([sum(p[r][2] for r in range(world)) for p in per_rank]) / len(structures))}
+
+
+def gather_rank_stats(dist, backend, dev, values):
+    """[values of rank 0, values of rank 1, ...] on every rank (a list of floats per rank; no process group: just this process)."""
+    import torch
+    if dist is None:
+        return [list(map(float, values))]
+    t = torch.tensor(values, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.cpu()] for o in out]
 
 
 def self_launch(args):
@@ -374,7 +431,18 @@ def main():
             el = float(t.item())
         return el, z_
 
+    def timed_per_rank(n_steps):
+        """every rank's OWN time for n_steps (device-synchronised before and after, no barrier in between the ranks' loops)"""
+        barrier()
+        t0_ = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0_
+        return [r_[0] for r_ in gather_rank_stats(dist, args.backend, dev, [own])]
+
     elapsed, z = timed(args.warmup, args.steps)
+    rank_times = timed_per_rank(args.steps) if world > 1 else None
     assert args.no_check or torch.isfinite(z).all()
     status = model.status()
 
@@ -452,6 +520,7 @@ def main():
             if hit:
                 traffic = 2.0 * hit[0]["fetch_bytes_per_dispatch_raw"] + hit[0]["write_bytes_per_dispatch"]
         bound = "hbm" if hbm_frac >= mfma_frac else "mfma"
+        per_nn, frac_rocprof = per_nn_table(config, kern, n1, traffic_file)
         roofline = {
             "kernel": f"k_edge<{nn_max}> = one whole state-update layer: edges, attention, the layer's output MLPs (finish phase) and the next "
                       f"layer's per-atom records (prepare phase) (dominant: {dom['avg_launch_ms'] * dom['launches_per_forward'] / t_all:.0%} of the layer time)",
@@ -460,6 +529,10 @@ def main():
             "peak": PEAK_HBM_GBS if bound == "hbm" else PEAK_F16_TFLOPS,
             "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
             "frac": max(hbm_frac, mfma_frac),
+            # the same fraction from the COMMITTED rocprofv3 kernel trace (average duration of this kernel in the hash-stamped profile
+            # of this build, profiles/traffic_*.json; the profiler adds ~5 % to a launch and the trace may come from another box of
+            # the pool): null when the committed profile was taken on other kernel sources
+            "frac_rocprof": frac_rocprof.get(nn_max) if bound == "hbm" else None,
             "traffic": traffic,
             # SURVEY 8d definition (B): compulsory bytes with a perfect cache - own state read + written (1,024 B) and 4 B of ids per edge
             "traffic_over_compulsory": (traffic / ((1024.0 + 4.0 * nn_max) * n1)) if traffic else None,
@@ -478,6 +551,8 @@ def main():
             "useful_definition": "reference-formulation FLOPs of the edge part (SURVEY 8d: 2 x 36,376 x nn per atom) / time; the kernel executes "
                                  "fewer (first-layer linearity) on the f16 pipe, so this is NOT a fraction of any peak",
             "traffic_note": traffic_note,
+            # every layer kernel, not only the dominant one: the worst fraction is visible in the line
+            "per_nn": per_nn,
         }
     whole = {"layers_ms": layers_ms, "forward_ms": fwd_ms, "launches": n_launch,
              "forward_ms_p10_p90": [float(np.percentile(fwd_all, 10)), float(np.percentile(fwd_all, 90))],
@@ -575,6 +650,10 @@ def main():
                        "precision": args.precision, "fp32_reruns_in_timed_region": status["n_fp32_rerun"],
                        "sharding": f"{world} rank(s), independent structures per rank, no data-path collective"},
             "weak_value": weak_value,
+            # N > 1: every rank's own time for the same number of steps (a separate pass right behind the timed one) - a straggling GPU
+            # or rank is visible here, the headline takes the max over ranks
+            "per_rank": None if rank_times is None else [{"rank": r_, "seconds": t_, "value": args.steps * args.batch / t_} for r_, t_ in enumerate(rank_times)],
+            "rank_time_max_over_min": None if rank_times is None else max(rank_times) / min(rank_times),
             "value_exact_fp32": exact["value"] if exact else None,
             "exact_fp32_max_abs_vs_timed_output": exact["max_abs_vs_timed_output"] if exact else None,
             "parity_max_abs": parity,
@@ -589,7 +668,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(config, sd, args.atoms, args.cpu_budget, key)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             if "reference_equivalent" in out["cpu_baseline"]:
-                out["speedup_vs_reference_equivalent_cpu"] = out["value"] / out["cpu_baseline"]["reference_equivalent"]["structures_per_s"]
+                # an ESTIMATE: rho (reference / port) was measured on another machine - the build container, 8 threads
+                # (profiles/r02_cpu_rho.json) - and multiplies the port's time at 8 threads on this host
+                out["speedup_vs_reference_equivalent_cpu_estimate"] = out["value"] / out["cpu_baseline"]["reference_equivalent"]["structures_per_s"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -154,11 +154,8 @@ int pesto_forward_frames(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_
  *                           than 64 atoms or coincident atoms;
  *   PESTO_BATCH_INDEPENDENT each structure as in its own call, which is what the reference's bulk inference loops do (one
  *                           structure per forward): max(D) and the wrap target are per structure, so results do not depend on
- *                           how structures were grouped into launches (what sharding over GPUs relies on). Bit for bit under
- *                           F16_SPLIT / FP32, and under AUTO as long as no launch is repeated on the fp32 kernels: the range guard
- *                           is one flag per LAUNCH, so a structure that shares a launch with an overflowing batch mate is computed
- *                           by the exact kernels there and by the split kernels alone (both inside the 1e-4 bound; pesto_get_status
- *                           tells whether a repeat happened - afterwards the handle runs fp32 first and is independent again).
+ *                           how structures were grouped into launches (what sharding over GPUs relies on) - bit for bit under
+ *                           every precision: under AUTO the range guard and its fp32 repeat are per structure (pesto_precision).
  * Returns after every z_out[b] is filled. */
 enum { PESTO_BATCH_COLLATED = 0, PESTO_BATCH_INDEPENDENT = 1 };
 int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, const int64_t* R, const int32_t* k,
@@ -178,12 +175,19 @@ int pesto_forward_batch(pesto_model* m, int32_t n_struct, const int64_t* N, cons
  * Inputs as pesto_forward_batch, plus two compact forms that cut the H2D volume from 392 to 145 bytes per atom:
  *   ids_kind PESTO_IDS_UINT16  ids_topk0[b] as uint16 (0-based within the structure, N_b <= 65,536);
  *   q_index != NULL            instead of the dense one-hot q0[b]: uint8 [N_b, n_index] block-local indices, expanded on the GPU to
- *                              q0[i][index_offsets[c] + q_index[i][c]] = 1 (encode_features, src/data_encoding.py:78-84). */
+ *                              q0[i][index_offsets[c] + q_index[i][c]] = 1 (encode_features, src/data_encoding.py:78-84);
+ *   q_index == NULL, n_index > 0   dense q0[b] AND the block offsets: the library looks for the indices itself while it reads the rows
+ *                              for packing (every block of every row exactly one 1.0f, everything else 0.0f) and ships them as bytes; a
+ *                              launch with one row that is not one-hot travels dense - same bits either way. */
 int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* N, const int64_t* R, const int32_t* k,
                                const float* const* X, const void* const* ids_topk0, int32_t ids_kind,
                                const float* const* q0, const uint8_t* const* q_index, int32_t n_index, const int32_t* index_offsets,
                                const int32_t* const* res_of_atom, float* const* z_out, int32_t batch_mode, int32_t* ticket);
 int pesto_forward_batch_wait(pesto_model* m, int32_t ticket);
+/* test / measurement hook: enabled != 0 makes pesto_forward_batch_submit do its HOST half only (validation, one-hot detection, packing
+ * into the pinned slot) and queue nothing on the GPU; the wait returns zero logits. profiles/host_packing.py uses it to measure the
+ * packing rate one rank's CPU sustains with the GPU idle. */
+int pesto_debug_host_only(pesto_model* m, int32_t enabled);
 
 /* bytes of device workspace a batch of (N, R) needs (ownership: SURVEY 8b) */
 int pesto_workspace_bytes(const pesto_model* m, int64_t N, int64_t R, int64_t* bytes);

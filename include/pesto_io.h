@@ -77,6 +77,12 @@ int pesto_io_encode(const pesto_structure* s, int32_t n0, float* X, float* q0, i
 int pesto_io_write_pdb(const pesto_structure* s, const float* bfactor, int64_t n_values, const char* path);
 int pesto_io_format_pdb(pesto_structure* s, const float* bfactor, int64_t n_values, const char** text, int64_t* len);
 
+/* replaces: what Model.forward needs from the dense residue mask M [N,R] of encode_structure (src/data_encoding.py:73; used by
+ * StatePoolLayer, src/model_operations.py:199): res_of_atom[i] = the one column with M[i][r] > 0.5. PESTO_IO_ERR_INVALID for a row
+ * with zero or several members or an empty column (the reference's dense softmax degenerates there). Host arrays; the mask on the
+ * GPU is reduced by pesto_mask_to_segments (pesto_hip.h). */
+int pesto_io_mask_to_segments(const float* M, int64_t N, int64_t R, int32_t* res_of_atom);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch", "pesto_get_kernel_timing",
     "pesto_set_precision", "pesto_get_status", "pesto_debug_select", "pesto_forward_structures",
     "pesto_mask_to_segments", "pesto_debug_edge_mode", "pesto_forward_batch_submit", "pesto_forward_batch_wait",
-    "pesto_set_async_auto",
+    "pesto_set_async_auto", "pesto_debug_host_only",
 ]
 
 _lib = None
@@ -104,6 +104,7 @@ def load():
     lib.pesto_forward_batch_wait.argtypes = [c_p, i32]
     lib.pesto_set_precision.argtypes = [c_p, i32]
     lib.pesto_set_async_auto.argtypes = [c_p, i32]
+    lib.pesto_debug_host_only.argtypes = [c_p, i32]
     lib.pesto_get_status.argtypes = [c_p, P(i32), P(i64), P(i64)]
     lib.pesto_debug_select.argtypes = [c_p, i32, i32]
     lib.pesto_debug_edge_mode.argtypes = [c_p, i32]

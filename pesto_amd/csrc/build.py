@@ -77,7 +77,7 @@ def build_io(force=False, verbose=True):
     hdr = os.path.join(HERE, "..", "..", "include", "pesto_io.h")
     if force or _stale(IO_OUT, [src, hdr]):
         cxx = shutil.which("g++") or hipcc()
-        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", IO_OUT, src]
+        cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", IO_OUT, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

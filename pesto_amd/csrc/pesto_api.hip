@@ -86,6 +86,8 @@ struct pesto_model {
     DevBuf col_meta, col_ids, col_roa;    // pesto_forward_batch: per-structure table, collated ids / residue columns
     DevBuf dmax, roa_f;                   // per-frame max(D) words; residue column per atom of a frame batch
     std::vector<float> pack;              // host packing buffer for strided host frames
+    std::vector<uint8_t> qidx_host;       // pesto_forward_batch_submit: block-local feature indices found in a dense one-hot q0
+    bool host_only = false;               // pesto_debug_host_only: submit packs and validates but queues no device work
     std::vector<int> seg_host;            // structure end offsets of the last pesto_forward_structures call (H2D source)
     // pesto_forward_batch_submit / _wait: two staging slots (pinned host + device), one copy stream
     struct BatchSlot {
@@ -531,6 +533,12 @@ int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_
     return 0;
 }
 
+int pesto_debug_host_only(pesto_model* m, int32_t enabled) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    m->host_only = enabled != 0;
+    return 0;
+}
+
 int pesto_debug_edge_mode(pesto_model* m, int32_t mode) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     if (mode < 0 || mode > 5)
@@ -806,8 +814,10 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
     if (n_struct < 1 || !N || !R || !k || !X || !ids_topk0 || (!q0 && !q_index) || !res_of_atom || !z_out || !ticket) return fail(PESTO_ERR_INVALID, "bad arguments");
     if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64 && ids_kind != PESTO_IDS_UINT16) return fail(PESTO_ERR_INVALID, "ids_kind must be 16, 32 or 64");
     if (q_index && (n_index < 1 || n_index > 3 || !index_offsets)) return fail(PESTO_ERR_INVALID, "q_index needs 1..3 index columns and their block offsets");
+    const bool detect = !q_index && n_index > 0;      // dense q0 + the block offsets: find the indices while packing (below)
+    if (detect && (n_index > 3 || !index_offsets)) return fail(PESTO_ERR_INVALID, "index_offsets: 1..3 block offsets");
     const int n0 = m->cfg.n0, n_out = m->cfg.n_out;
-    if (q_index)
+    if (q_index || detect)
         for (int c = 0; c < n_index; ++c)
             if (index_offsets[c] < 0 || index_offsets[c] >= n0 || (c && index_offsets[c] <= index_offsets[c - 1])) return fail(PESTO_ERR_INVALID, "index_offsets must ascend inside [0, n0)");
     pesto_model::BatchSlot& b = m->slot[m->next_slot];
@@ -824,6 +834,40 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
         b.roff[s_] = (int)RT; b.rcount[s_] = (int)R[s_];
         NT += N[s_]; RT += R[s_]; IT += N[s_] * k[s_];
         if (NT > 0x7ffffff0 / 96) return fail(PESTO_ERR_INVALID, "batch too large");
+    }
+    // dense one-hot features -> byte indices, found while the rows are read for packing anyway: every block of every row must hold
+    // exactly one 1.0f and zeros (encode_features, src/data_encoding.py:78-84); one row that does not makes the launch travel dense
+    std::vector<const uint8_t*> qi_ptr;
+    if (detect) {
+        m->qidx_host.resize((size_t)NT * n_index);
+        bool onehot = true;
+        int bounds[4] = {0, 0, 0, 0};
+        for (int c = 0; c < n_index; ++c) bounds[c] = index_offsets[c];
+        bounds[n_index] = n0;
+        for (int s_ = 0; s_ < n_struct && onehot; ++s_) {
+            const float* qs = q0[s_];
+            uint8_t* dst = m->qidx_host.data() + (size_t)meta[s_].off * n_index;
+            for (int64_t i = 0; i < N[s_] && onehot; ++i) {
+                const float* row = qs + i * n0;
+                for (int c = 0; c < n_index; ++c) {
+                    int at = -1, ones = 0, other = 0;
+                    for (int f = bounds[c]; f < bounds[c + 1]; ++f) {
+                        if (row[f] == 1.0f) { at = f; ++ones; }
+                        else if (row[f] != 0.0f) ++other;
+                    }
+                    if (ones != 1 || other != 0 || at - bounds[c] > 255) { onehot = false; break; }
+                    dst[i * n_index + c] = (uint8_t)(at - bounds[c]);
+                }
+                for (int f = 0; f < bounds[0] && onehot; ++f) if (row[f] != 0.0f) onehot = false;      // (features in front of the first block)
+            }
+        }
+        if (onehot) {
+            qi_ptr.resize((size_t)n_struct);
+            for (int s_ = 0; s_ < n_struct; ++s_) qi_ptr[s_] = m->qidx_host.data() + (size_t)meta[s_].off * n_index;
+            q_index = qi_ptr.data();
+        } else {
+            n_index = 0;
+        }
     }
     HIP_TRY(hipSetDevice(m->device));
     if (!m->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
@@ -872,6 +916,15 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
     }
     b.n_struct = n_struct; b.ids_kind = ids_kind; b.n_index = q_index ? n_index : 0; b.mode = batch_mode; b.NT = NT; b.RT = RT;
     for (int c = 0; c < 3; ++c) b.index_offsets[c] = (q_index && c < n_index) ? index_offsets[c] : 0;
+    if (m->host_only) {      // pesto_debug_host_only: the host half only (what one rank's CPU must sustain), nothing queued
+        memset(b.h_z, 0, zbytes);
+        b.h_flag[0] = b.h_flag[1] = 0;
+        HIP_TRY(hipEventRecord(b.ev_done, m->stream));
+        b.busy = true;
+        *ticket = m->next_slot;
+        m->next_slot ^= 1;
+        return 0;
+    }
     // the slot's device buffer may still be read by the launch that used it last: that launch was waited for (busy == false)
     HIP_TRY(hipMemcpyAsync(b.d_in.p, b.h_in, total, hipMemcpyHostToDevice, m->copy_stream));
     HIP_TRY(hipEventRecord(b.ev_h2d, m->copy_stream));

@@ -641,4 +641,28 @@ int pesto_io_write_pdb(const pesto_structure* s, const float* bfactor, int64_t n
     return 0;
 }
 
+
+/* dense residue mask -> residue column per atom, one pass over the rows (the numpy form makes four) */
+int pesto_io_mask_to_segments(const float* M, int64_t N, int64_t R, int32_t* res_of_atom) {
+    if (!M || !res_of_atom || N < 1 || R < 1 || R > 0x7fffffff) return fail(PESTO_IO_ERR_INVALID, "bad arguments");
+    std::vector<unsigned char> seen((size_t)R, 0);
+    for (int64_t i = 0; i < N; ++i) {
+        const float* row = M + i * R;
+        // branch-free so that the compiler vectorises the row scan: members = sum of (M > 0.5), at = sum of r (M > 0.5) - the member's
+        // column when there is exactly one
+        int members = 0, at = 0;
+        for (int r = 0; r < (int)R; ++r) {
+            const int hit = row[r] > 0.5f ? 1 : 0;
+            members += hit;
+            at += hit * r;
+        }
+        if (members != 1) return fail(PESTO_IO_ERR_INVALID, "M: atom %lld belongs to %d residues (every atom must belong to exactly one)", (long long)i, members);
+        res_of_atom[i] = (int32_t)at;
+        seen[(size_t)at] = 1;
+    }
+    for (int64_t r = 0; r < R; ++r)
+        if (!seen[(size_t)r]) return fail(PESTO_IO_ERR_INVALID, "M: residue column %lld is empty", (long long)r);
+    return 0;
+}
+
 }  // extern "C"

@@ -96,6 +96,11 @@ class Model:
             _lib.check(_lib.load().pesto_debug_select(self._handle, *self._debug))
         return self
 
+    def debug_host_only(self, enabled=True):
+        """Measurement hook (pesto_debug_host_only): forward_batch_submit does its host half only; the wait returns zeros."""
+        _lib.check(_lib.load().pesto_debug_host_only(self._ensure(), 1 if enabled else 0))
+        return self
+
     def debug_edge_mode(self, mode=0):
         """Test hook (pesto_debug_edge_mode): 0 = work decomposition of the state-update kernel chosen per launch, 1 = rendezvous
         mode, 2 = node-wave mode. Results must not depend on it."""
@@ -301,7 +306,11 @@ class Model:
         Xp, Ip, Qp, Ap, Zp = (arr(ctypes.c_void_p) for _ in range(5))
         kind = None
         for b, (X, ids, q0, M) in enumerate(structures):
-            roa, R = mask_to_segments(M) if self.validate else (np.asarray(M.detach().cpu().numpy() if _is_torch(M) else M).argmax(1).astype(np.int32), int(M.shape[1]))
+            Mh = M.detach().cpu().numpy() if _is_torch(M) else np.asarray(M)
+            if Mh.ndim == 1:                      # the compact forms forward_batch_submit takes: res_of_atom [N] and uint8 feature indices
+                roa, R = Mh.astype(np.int32), (int(Mh.max()) + 1 if Mh.size else 0)
+            else:
+                roa, R = mask_to_segments(Mh) if self.validate else (Mh.argmax(1).astype(np.int32), int(Mh.shape[1]))
             Xn = np.ascontiguousarray(X.detach().cpu().numpy() if _is_torch(X) else X, dtype=np.float32)
             idn = ids.detach().cpu().numpy() if _is_torch(ids) else np.asarray(ids)
             idn = np.ascontiguousarray(idn.astype(np.int32) if idn.dtype != np.int64 else idn)
@@ -309,7 +318,14 @@ class Model:
                 kind = idn.dtype
             elif idn.dtype != kind:
                 idn = np.ascontiguousarray(idn.astype(kind))
-            qn = np.ascontiguousarray(q0.detach().cpu().numpy() if _is_torch(q0) else q0, dtype=np.float32)
+            qh = q0.detach().cpu().numpy() if _is_torch(q0) else np.asarray(q0)
+            if qh.dtype == np.uint8:              # indices -> the dense one-hot rows this (synchronous) entry point uploads
+                offs = self.ONEHOT_OFFSETS[n0]
+                dense = np.zeros((qh.shape[0], n0), np.float32)
+                for c, o in enumerate(offs):
+                    dense[np.arange(qh.shape[0]), o + qh[:, c].astype(np.int64)] = 1.0
+                qh = dense
+            qn = np.ascontiguousarray(qh, dtype=np.float32)
             roa = np.ascontiguousarray(roa.detach().cpu().numpy() if _is_torch(roa) else roa, dtype=np.int32)
             N = Xn.shape[0]
             if idn.ndim != 2 or idn.shape[0] != N:
@@ -331,8 +347,12 @@ class Model:
         """First half of forward_batch (pesto_forward_batch_submit): packs the structures into a pinned staging slot and queues the
         H2D copy, the forward and the D2H copy; returns a ticket at once. Up to two tickets may be in flight, so the packing and the copy
         of launch t + 1 overlap the kernels of launch t (the reference feeds its loop from DataLoader workers the same way,
-        interfaceome/apply_model.py:50-82). ``compact``: neighbour ids as uint16 and - when q0 is one-hot in the reference's feature
-        blocks - features as byte indices (145 instead of 392 bytes per atom over PCIe; expanded on the GPU, same bits)."""
+        interfaceome/apply_model.py:50-82). ``compact``: neighbour ids travel as uint16 and one-hot features as byte indices (145
+        instead of 392 bytes per atom over PCIe; expanded on the GPU, same bits) - the library finds the indices itself while it packs
+        the rows (a launch with a row that is not one-hot in the reference's feature blocks travels dense).
+        Per structure (X, ids_topk0, q, M) as forward_batch takes them; to skip the host work a caller that already has them may
+        pass q as the uint8 index array [N, n_index] (encode_features' argmax per block) and M as res_of_atom [N] (int32, the
+        residue column of every atom, 0 .. R-1) - the Python layer then touches no array element."""
         h = self._ensure()
         lib = _lib.load()
         n0, n_out = self.config["em"]["N0"], self.config["dm"]["N2"]
@@ -344,45 +364,56 @@ class Model:
         Np, Rp, kp = arr(ctypes.c_int64), arr(ctypes.c_int64), arr(ctypes.c_int32)
         Xp, Ip, Qp, Jp, Ap, Zp = (arr(ctypes.c_void_p) for _ in range(6))
         zs, keep = [], []
-        use_idx = compact and offs is not None
+        host = lambda a: a.detach().cpu().numpy() if _is_torch(a) else np.asarray(a)
+        n_idx_given = sum(1 for s in structures if host(s[2]).dtype == np.uint8)
+        if n_idx_given not in (0, nb):
+            raise ValueError("either every structure passes q as uint8 indices or none does")
+        if n_idx_given and offs is None:
+            raise ValueError(f"no one-hot feature blocks known for N0 = {n0}")
         id_dtype = np.uint16 if compact and all(int(np.shape(s[0])[0]) <= 65536 for s in structures) else np.int32
         for b, (X, ids, q0, M) in enumerate(structures):
-            roa, R = mask_to_segments(M) if self.validate else (np.asarray(M.detach().cpu().numpy() if _is_torch(M) else M).argmax(1).astype(np.int32), int(M.shape[1]))
-            Xn = np.ascontiguousarray(X.detach().cpu().numpy() if _is_torch(X) else X, dtype=np.float32)
-            idr = ids.detach().cpu().numpy() if _is_torch(ids) else np.asarray(ids)
-            if id_dtype is np.uint16 and idr.size and (int(idr.min()) < 0 or int(idr.max()) > 65535):
-                # narrowing would wrap an invalid id into a valid one: hand the table over as it is (the library rejects it)
-                raise ValueError(f"structure {b}: ids_topk has entries outside [0, N)")
-            idn = np.ascontiguousarray(idr.astype(id_dtype, copy=False))
-            qn = np.ascontiguousarray(q0.detach().cpu().numpy() if _is_torch(q0) else q0, dtype=np.float32)
-            roa = np.ascontiguousarray(roa, dtype=np.int32)
+            Mh = host(M)
+            if Mh.ndim == 1:                        # res_of_atom given: the library checks its range, the forward that every residue has an atom
+                roa = np.ascontiguousarray(Mh, dtype=np.int32)
+                R = int(roa.max()) + 1 if roa.size else 0
+            elif self.validate:
+                roa, R = mask_to_segments(Mh)
+                roa = np.ascontiguousarray(roa, dtype=np.int32)
+            else:
+                roa, R = np.ascontiguousarray(Mh.argmax(1), dtype=np.int32), int(Mh.shape[1])
+            Xn = np.ascontiguousarray(host(X), dtype=np.float32)
+            idr = host(ids)
+            if idr.dtype != id_dtype:
+                if id_dtype is np.uint16 and idr.size and (int(idr.min()) < 0 or int(idr.max()) > 65535):
+                    # narrowing would wrap an invalid id into a valid one
+                    raise ValueError(f"structure {b}: ids_topk has entries outside [0, N)")
+                idr = idr.astype(id_dtype)
+            idn = np.ascontiguousarray(idr)
             N = Xn.shape[0]
             if idn.ndim != 2 or idn.shape[0] != N:
                 raise ValueError(f"structure {b}: ids_topk must be [N, k] with N={N}")
-            self._check_shapes(N, Xn.shape, qn.shape, roa.shape, n0)
-            qi = None
-            if use_idx:      # one-hot rows -> block-local byte indices (exactly one 1 per block, else fall back to the dense form)
-                bounds = list(offs) + [n0]
-                cols = [qn[:, bounds[c]:bounds[c + 1]] for c in range(len(offs))]
-                if all(bool(((c == 0) | (c == 1)).all()) and bool((np.count_nonzero(c, 1) == 1).all()) for c in cols):
-                    qi = np.ascontiguousarray(np.stack([c.argmax(1) for c in cols], 1).astype(np.uint8))
-                else:
-                    use_idx = False
-                    for kb in keep:
-                        kb[4] = None
+            qh = host(q0)
+            if n_idx_given:
+                qn = np.ascontiguousarray(qh)
+                if qn.shape != (N, len(offs)):
+                    raise ValueError(f"structure {b}: q as indices must be uint8 [N, {len(offs)}], got {qn.shape}")
+                self._check_shapes(N, Xn.shape, (N, n0), roa.shape, n0)
+            else:
+                qn = np.ascontiguousarray(qh, dtype=np.float32)
+                self._check_shapes(N, Xn.shape, qn.shape, roa.shape, n0)
             z = np.empty((R, n_out), dtype=np.float32)
-            keep.append([Xn, idn, qn, roa, qi])
+            keep.append((Xn, idn, qn, roa))
             zs.append(z)
             Np[b], Rp[b], kp[b] = N, R, idn.shape[1]
-            Xp[b], Ip[b], Qp[b], Ap[b], Zp[b] = Xn.ctypes.data, idn.ctypes.data, qn.ctypes.data, roa.ctypes.data, z.ctypes.data
-        if use_idx:
-            for b, kb in enumerate(keep):
-                Jp[b] = kb[4].ctypes.data
-        io = (ctypes.c_int32 * 3)(*(list(offs) + [0] * (3 - len(offs)))) if use_idx else None
+            Xp[b], Ip[b], Ap[b], Zp[b] = Xn.ctypes.data, idn.ctypes.data, roa.ctypes.data, z.ctypes.data
+            (Jp if n_idx_given else Qp)[b] = qn.ctypes.data
+        # dense q + block offsets: the library detects one-hot rows while packing (compact only)
+        use_offs = offs is not None and (n_idx_given or compact)
+        io = (ctypes.c_int32 * 3)(*(list(offs) + [0] * (3 - len(offs)))) if use_offs else None
         kind = {np.dtype(np.uint16): _lib.IDS_UINT16, np.dtype(np.int32): _lib.IDS_INT32}[np.dtype(id_dtype)]
         t = ctypes.c_int32(-1)
-        _lib.check(lib.pesto_forward_batch_submit(h, nb, Np, Rp, kp, Xp, Ip, kind, None if use_idx else Qp, Jp if use_idx else None,
-                                                  len(offs) if use_idx else 0, io, Ap, Zp,
+        _lib.check(lib.pesto_forward_batch_submit(h, nb, Np, Rp, kp, Xp, Ip, kind, None if n_idx_given else Qp, Jp if n_idx_given else None,
+                                                  len(offs) if use_offs else 0, io, Ap, Zp,
                                                   _lib.BATCH_INDEPENDENT if independent else _lib.BATCH_COLLATED, ctypes.byref(t)))
         self._tickets = getattr(self, "_tickets", {})
         self._tickets[t.value] = zs          # the logits arrays must stay alive until the wait (the packed inputs need not)

@@ -226,21 +226,30 @@ def gather_results(local, n_total, n_out, group=None, device=None, failed_ranks=
     return out
 
 
-def forward_sharded(forward_fn, structures, n_out, max_atoms=24576, group=None, device=None):
+def forward_sharded(forward_fn, structures, n_out, max_atoms=24576, group=None, device=None, timings=None):
     """Shard ``structures`` over the ranks of the (already initialised) process group, run them, gather all results
-    on every rank.  Single-process (no process group): runs everything locally."""
+    on every rank.  Single-process (no process group): runs everything locally.
+    ``timings`` (optional dict): receives this rank's seconds in its own launches ("local_s"), in the result gather ("gather_s") and
+    the structures / atoms it owned - a straggler shows up as a large local_s, an idle rank as a large gather_s."""
+    import time
     import torch.distributed as dist
     sizes = [np.asarray(s[0]).shape[0] for s in structures]
+    t0 = time.perf_counter()
     if not (dist.is_available() and dist.is_initialized()):
         local = forward_local(forward_fn, structures, list(range(len(structures))), max_atoms)
+        if timings is not None:
+            timings.update(local_s=time.perf_counter() - t0, gather_s=0.0, structures=len(structures), atoms=int(sum(sizes)))
         return [local[i] for i in range(len(structures))]
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     mine = partition(sizes, world)[rank]
     # a rank whose structures ALL fail must still enter the collective (the others are already waiting in it): the verdict is taken
     # from the gathered descriptors, identically on every rank
     local = forward_local(forward_fn, structures, mine, max_atoms, raise_if_all_failed=False)
+    t1 = time.perf_counter()
     failed = []
     out = gather_results(local, len(structures), n_out, group=group, device=device, failed_ranks=failed)
+    if timings is not None:
+        timings.update(local_s=t1 - t0, gather_s=time.perf_counter() - t1, structures=len(mine), atoms=int(sum(sizes[i] for i in mine)))
     if failed:
         raise AllStructuresFailed(f"every structure of rank(s) {failed} failed (see that rank's log): a systemic problem, not a bad input")
     return out

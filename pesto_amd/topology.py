@@ -138,7 +138,21 @@ def mask_to_segments(M):
         if not bool(Mb.any(0).all()):
             raise ValueError("M: empty residue column")
         return torch.argmax(Mb.to(torch.int8), dim=1).to(torch.int32), int(M.shape[1])
-    Mn = _np(M) > 0.5
+    Mh = _np(M)
+    if Mh.ndim == 2 and Mh.dtype == np.float32 and Mh.flags.c_contiguous and Mh.size:
+        # one native pass over the rows (libpesto_io.so, host only) instead of four numpy passes over the dense mask: this reduction is
+        # the largest host cost per structure of the bulk path when callers hand over the reference's dense M (profiles/r04_host_packing.json)
+        try:
+            from . import structure_io
+            lib = structure_io.load()
+        except Exception:
+            lib = None
+        if lib is not None:
+            roa = np.empty(Mh.shape[0], np.int32)
+            if lib.pesto_io_mask_to_segments(Mh.ctypes.data, Mh.shape[0], Mh.shape[1], roa.ctypes.data) != 0:
+                raise ValueError(lib.pesto_io_last_error().decode())
+            return roa, int(Mh.shape[1])
+    Mn = Mh > 0.5
     if not np.all(Mn.sum(1) == 1):
         raise ValueError("M: every atom must belong to exactly one residue")
     if not np.all(Mn.any(0)):

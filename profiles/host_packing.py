@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""What the HOST side of the sharded bulk path costs, with the GPU idle (GPU box): python profiles/host_packing.py [processes] [seconds]
+
+Eight ranks must pack 8 x 1,700 structures/s between them before the GPUs are the limit. Every process builds a handle, switches it
+to pesto_debug_host_only (pesto_forward_batch_submit then does its host half only - argument checks, one-hot detection, packing into
+the pinned staging slot - and queues nothing on the GPU) and pushes the config-4 work list (the 53 pdbs_test chains, compact forms as
+bench.py's config-4 leg hands them over, launches of <= 24,576 atoms) through sharding.forward_local for a fixed time. Reported per
+process and in total: structures/s of packing (wall clock), CPU seconds per structure (time.process_time of the process). A second pass
+with the DENSE per-structure forms (float one-hot features, dense residue mask, int32 ids) shows what the library's in-pack one-hot
+detection and the Python-side mask reduction cost."""
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def worker(rank, seconds, dense, q):
+    import bench
+    from pesto_amd import Model, sharding
+    from pesto_amd.config import CONFIGS
+    cfg = CONFIGS["i_v4_1"]
+    sd, _ = bench.load_weights(cfg)
+    m = Model(cfg, validate=False)
+    m.load_state_dict(sd)
+    structures, sizes, _ = bench.config4_structures(64, m)           # (GPU k-NN once, outside the timed region)
+    if dense:
+        out = []
+        for X, ids, qi, roa in structures:
+            q0 = np.zeros((X.shape[0], 30), np.float32); q0[np.arange(X.shape[0]), qi[:, 0]] = 1.0
+            M = np.zeros((X.shape[0], int(roa.max()) + 1), np.float32); M[np.arange(X.shape[0]), roa] = 1.0
+            out.append((X, ids.astype(np.int32), q0, M))
+        structures = out
+        m.validate = True
+    m.debug_host_only(True)
+    idx = list(range(len(structures)))
+    sharding.forward_local(m, structures, idx)                       # warm-up: pinned slots allocated
+    n, t0, c0 = 0, time.perf_counter(), time.process_time()
+    while time.perf_counter() - t0 < seconds:
+        sharding.forward_local(m, structures, idx)
+        n += len(structures)
+    q.put((rank, n, time.perf_counter() - t0, time.process_time() - c0))
+
+
+def run(procs, seconds, dense):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=worker, args=(r, seconds, dense, q)) for r in range(procs)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get() for _ in ps)
+    for p in ps:
+        p.join()
+    rate = [n / w for _, n, w, _ in res]
+    return {"processes": procs, "forms": "dense (float one-hot q, dense mask M, int32 ids; validate=True)" if dense else "compact (uint8 feature indices, res_of_atom, uint16 ids)",
+            "structures_per_s_total": float(sum(rate)), "structures_per_s_per_process": [float(r) for r in rate],
+            "host_cpu_s_per_structure": float(np.mean([c / n for _, n, _, c in res])),
+            "needed_for_8_gpus": 8 * 1700.0}
+
+
+if __name__ == "__main__":
+    procs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
+    out = {"host_cores": os.cpu_count(), "runs": [run(1, seconds, False), run(procs, seconds, False), run(procs, seconds, True)]}
+    print(json.dumps(out, indent=1))

@@ -42,3 +42,24 @@ def test_traffic_file_is_stamped():
     assert len(bench.source_hash()) == 16            # (whether it matches the tree decides if bench.py quotes the file)
     per = [v for k, v in t["kernels"].items() if "k_edge<64" in k][0]
     assert per["dispatches_per_forward"] == 8 and per["write_bytes_per_dispatch"] > 0
+
+
+def test_per_nn_table_and_rocprof_fraction():
+    """bench.py's per-kernel table: every layer kernel of the forward with its def-A fraction by HIP events and - only when the committed
+    profile carries the source hash of the build - by the rocprofv3 trace, its HBM-side traffic and traffic / compulsory bytes."""
+    cfg = CONFIGS["i_v4_1"]
+    n1 = 24001
+    kern = {f"edge_nn{nn}": {"launches_per_forward": 8, "avg_launch_ms": ms} for nn, ms in ((8, 0.0626), (16, 0.0937), (32, 0.1554), (64, 0.2705))}
+    table, frac_rp = bench.per_nn_table(cfg, kern, n1, None)
+    assert sorted(table) == ["16", "32", "64", "8"] and frac_rp == {}
+    assert abs(table["64"]["frac_def_A"] - 0.389) < 1e-3 and abs(table["8"]["frac_def_A"] - 0.253) < 1e-3      # the round-3 verdict's table
+    assert all(table[k]["frac_def_A_rocprof"] is None and table[k]["traffic"] is None for k in table)
+    tf = {"kernels": {"k_edge<64,12,false,true,true,4,true,12,false>": {"fetch_bytes_per_dispatch_raw": 80.0e6, "write_bytes_per_dispatch": 72.0e6}},
+          "rocprof_kernel_trace": {"kernels": {"k_edge<64,12,false,true,true,4,true,12,false>": {"calls": 136, "avg_ns": 300400.0}}}}
+    table, frac_rp = bench.per_nn_table(cfg, kern, n1, tf)
+    assert abs(frac_rp[64] - 0.350) < 1e-3 and abs(table["64"]["rocprof_avg_launch_ms"] - 0.3004) < 1e-6
+    assert abs(table["64"]["traffic"] - 232.0e6) < 1 and abs(table["64"]["traffic_over_compulsory"] - 232.0e6 / (1280.0 * n1)) < 1e-9
+    assert table["8"]["frac_def_A_rocprof"] is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"frac_rocprof"' in src and '"per_nn"' in src and "speedup_vs_reference_equivalent_cpu_estimate" in src
+    assert 'out["speedup_vs_reference_equivalent_cpu"]' not in src

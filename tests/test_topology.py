@@ -79,3 +79,35 @@ def test_synthetic_structure_contract():
     assert np.array_equal(X, X2)
     q123 = T.synthetic_structure(100, seed=4, n0=123)[2]
     assert q123.shape == (100, 123) and np.all(q123.sum(1) == 3)
+
+
+def test_mask_to_segments_native_pass_equals_the_numpy_contract():
+    """pesto_io_mask_to_segments (one native pass, used by mask_to_segments for host float32 masks) against the numpy statement of the
+    same contract: one member (> 0.5) per row, no empty column."""
+    import pytest
+    from pesto_amd.topology import mask_to_segments
+    rng = np.random.default_rng(5)
+    for n, R in ((1, 1), (17, 5), (300, 40), (1000, 333)):
+        roa = np.concatenate([np.arange(R), rng.integers(0, R, n - R)]) if n >= R else np.arange(n)
+        roa = rng.permutation(roa)[:n]
+        if len(set(roa.tolist())) < R:
+            roa[:R] = np.arange(R)
+        M = np.zeros((n, R), np.float32)
+        M[np.arange(n), roa] = 1.0
+        got, Rg = mask_to_segments(M)
+        assert Rg == R and got.dtype == np.int32 and np.array_equal(got, roa)
+        got64, _ = mask_to_segments(M.astype(np.float64))          # (the numpy path: other dtypes / layouts)
+        assert np.array_equal(got64, roa)
+    M = np.zeros((6, 3), np.float32); M[np.arange(6), [0, 1, 2, 0, 1, 2]] = 1.0
+    for bad in ("two", "none", "empty"):
+        Mb = M.copy()
+        if bad == "two":
+            Mb[2, 0] = 1.0
+        elif bad == "none":
+            Mb[4] = 0.0
+        else:
+            Mb[[2, 5]] = 0.0; Mb[[2, 5], 0] = 1.0
+        with pytest.raises(ValueError):
+            mask_to_segments(Mb)
+        with pytest.raises(ValueError):
+            mask_to_segments(Mb.astype(np.float64))
