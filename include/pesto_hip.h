@@ -215,6 +215,16 @@ int pesto_get_kernel_timing(pesto_model* m, double ms_sum[5], int32_t launches[5
 int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
                       void* ids_out, int32_t ids_kind, int32_t ptr_kind, void* stream);
 
+/* Companion of pesto_knn_collate, no reference counterpart: the reference takes whatever order torch.topk gives two neighbours at exactly
+ * the same float32 distance (src/data_encoding.py:98-99); this library orders them by index. The tables agree as SETS per neighbourhood
+ * unless such a tie straddles a layer's cut-off (ids_topk[:, :nn], src/model_operations.py:230): then one of two equally distant atoms is
+ * inside the first 8 / 16 / 32 / 64 and the choice is as arbitrary in the reference as here - but logits can differ (0.03 observed on one
+ * of 132,417 rows of the reference's pdbs_test set). This call reports those rows so that a caller can warn or pass its own table:
+ * flags_out[i] bit 0 / 1 / 2 / 3 = a tie of row i straddles the cut after column 8 / 16 / 32 / 64 of `ids` (the [n_total, 64] table of
+ * pesto_knn_collate for the same X / struct_offsets / k). One wave per row, one scan over the row's structure. */
+int pesto_knn_tie_rows(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
+                       const void* ids, int32_t ids_kind, uint8_t* flags_out, int32_t ptr_kind, void* stream);
+
 /* replaces: the caller-side post-op p = sigmoid(z) (apply_model.ipynb:160, interfaceome/apply_model.py:76) and the
  * residue -> atom expansion of encode_bfactor (src/structure.py:208-218) for per-residue predictions.
  * z [R,n_out] -> p_out [R,n_out] (may be NULL) and bfactor_out [n_out,N] channel-major (may be NULL):

@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch", "pesto_get_kernel_timing",
     "pesto_set_precision", "pesto_get_status", "pesto_debug_select", "pesto_forward_structures",
     "pesto_mask_to_segments", "pesto_debug_edge_mode", "pesto_forward_batch_submit", "pesto_forward_batch_wait",
-    "pesto_set_async_auto", "pesto_debug_host_only",
+    "pesto_set_async_auto", "pesto_debug_host_only", "pesto_knn_tie_rows",
 ]
 
 _lib = None
@@ -116,6 +116,7 @@ def load():
     lib.pesto_get_timing.argtypes = [c_p, P(ctypes.c_double), P(ctypes.c_double), P(i32)]
     lib.pesto_get_kernel_timing.argtypes = [c_p, P(ctypes.c_double), P(i32)]
     lib.pesto_knn_collate.argtypes = [c_p, i64, i32, c_p, c_p, i32, c_p, i32, i32, c_p]
+    lib.pesto_knn_tie_rows.argtypes = [c_p, i64, i32, c_p, c_p, i32, c_p, i32, c_p, i32, c_p]
     lib.pesto_stage_embed.argtypes = [c_p, i64, c_p, c_p]
     lib.pesto_stage_unpack.argtypes = [c_p, i64, i32, c_p, c_p, i32, c_p, c_p]
     lib.pesto_stage_layer.argtypes = [c_p, i32, c_p, c_p]

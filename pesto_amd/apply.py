@@ -44,11 +44,15 @@ def load_results(path):
     return {str(k): p[offs[i]:offs[i + 1]] for i, k in enumerate(keys)}
 
 
-def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=24576, workers=8, on_error=print, results_path=None):
+def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=24576, workers=8, on_error=print, results_path=None,
+                report_ties=True):
     """Returns {path: p} with p = sigmoid(z) as numpy [R, n_out] for every structure that could be processed.
     write=True also saves ``path[:-4] + suffix.format(i)`` for each output channel i (apply_model.ipynb:157-166).
     results_path: also write all probability tables into one bulk result file (save_results), the reference's HDF5 store.
-    ``model``: a pesto_amd.Model on a GPU; max_atoms: atoms per launch (about 24k fills an MI355X)."""
+    ``model``: a pesto_amd.Model on a GPU; max_atoms: atoms per launch (about 24k fills an MI355X).
+    report_ties: log (logging "pesto_amd.apply", WARNING) the structures in which two neighbours at exactly the same float32 distance
+    straddle a layer's neighbourhood cut-off - the rows on which the reference's torch.topk (src/data_encoding.py:98-99) may have chosen
+    the other atom, the one known source of logit differences beyond 1e-4 against the reference (pesto_knn_tie_rows)."""
     import torch
     n0 = model.config["em"]["N0"]
     dev = torch.device("cuda", model._gpu)
@@ -58,7 +62,7 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
     was_async = model.async_auto
     model.set_async_auto(True)
     try:
-        _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_error, results, dev, n0)
+        _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_error, results, dev, n0, report_ties)
     finally:
         model.synchronize()
         model.set_async_auto(was_async)
@@ -67,7 +71,11 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
     return results
 
 
-def _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_error, results, dev, n0):
+def _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_error, results, dev, n0, report_ties):
+    import logging
+    log = logging.getLogger("pesto_amd.apply")
+    used_cuts = sorted({int(l["nn"]) for l in model.config["sum"]})
+    cut_mask = sum(1 << {8: 0, 16: 1, 32: 2, 64: 3}[c] for c in used_cuts)
     import torch
     with ThreadPoolExecutor(max_workers=workers) as pool:
         loads = [(p, pool.submit(_load, p, n0)) for p in pdb_filepaths]
@@ -84,18 +92,23 @@ def _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_erro
             """post-op + D2H of the launch in flight -> host arrays (None when nothing is in flight)"""
             if not in_flight:
                 return None
-            group, sizes, r_off, z, roa = in_flight.pop()
+            group, sizes, r_off, z, roa, ties = in_flight.pop()
             p, bf = model.postprocess(z, roa)
-            return group, sizes, r_off, p.cpu().numpy(), bf.cpu().numpy()
+            return group, sizes, r_off, p.cpu().numpy(), bf.cpu().numpy(), (ties.cpu().numpy() if ties is not None else None)
 
         def hand_out(done):
             """slice a fetched launch per structure, queue its b-factor files (host only: runs while the GPU computes the next launch)"""
             if done is None:
                 return
-            group, sizes, r_off, p, bf = done
+            group, sizes, r_off, p, bf, ties = done
             a_off = np.cumsum([0] + sizes)
             for i, (path, s, *_rest) in enumerate(group):
                 results[path] = p[r_off[i]:r_off[i + 1]]
+                if ties is not None:
+                    n_t = int(np.count_nonzero(ties[a_off[i]:a_off[i + 1]] & cut_mask))
+                    if n_t:
+                        log.warning("%s: %d atom(s) with an exact distance tie across a neighbourhood cut-off (nn in %s): the reference's "
+                                    "torch.topk may pick the other atom there", path, n_t, used_cuts)
                 if write:
                     for c in range(bf.shape[0]):
                         out = path[:-4] + suffix.format(c)
@@ -112,8 +125,9 @@ def _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_erro
             done = fetch()                                                              # the previous launch (the GPU had the packing time)
             X, q, roa = torch.from_numpy(Xh).to(dev), torch.from_numpy(qh).to(dev), torch.from_numpy(rh).to(dev)
             ids = model.knn_collate(X, sizes)
+            ties = model.knn_tie_rows(X, sizes, ids) if report_ties else None
             z = model.forward_segments(X, ids, q, roa, int(r_off[-1]), sizes=sizes)    # one call per structure, semantically
-            in_flight.append((group, sizes, r_off, z, roa))
+            in_flight.append((group, sizes, r_off, z, roa, ties))
             hand_out(done)
 
         group, atoms = [], 0

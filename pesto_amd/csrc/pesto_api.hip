@@ -1021,6 +1021,45 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
     return 0;
 }
 
+int pesto_knn_tie_rows(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
+                       const void* ids, int32_t ids_kind, uint8_t* flags_out, int32_t ptr_kind, void* stream) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (n_total < 1 || n_total > 0x7ffffff0 / 96 || n_struct < 1 || !struct_offsets || !X || !ids || !flags_out || k < 1 || k > KMAX)
+        return fail(PESTO_ERR_INVALID, "bad arguments");
+    if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
+    if (ptr_kind != PESTO_PTR_HOST && ptr_kind != PESTO_PTR_DEVICE) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
+    if (struct_offsets[0] != 0 || struct_offsets[n_struct] != n_total) return fail(PESTO_ERR_INVALID, "struct_offsets must span [0, n_total]");
+    for (int s = 0; s < n_struct; ++s)
+        if (struct_offsets[s + 1] <= struct_offsets[s]) return fail(PESTO_ERR_INVALID, "empty or unordered structure %d", s);
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
+    if (m->knn_off.ensure(((size_t)2 * n_struct + 1) * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    hipStream_t st = ptr_kind == PESTO_PTR_DEVICE ? (hipStream_t)stream : (stream ? (hipStream_t)stream : m->stream);
+    Sequence seq(m, st);
+    if (seq.rc) return seq.rc;
+    HIP_TRY(hipMemcpyAsync(m->knn_off.p, struct_offsets, ((size_t)n_struct + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));           // struct_offsets is the caller's: finish the copy before returning
+    if (ptr_kind == PESTO_PTR_DEVICE) {
+        launch_knn_ties(st, (int)n_total, n_struct, m->knn_off.as<int>(), X, k, ids, ids_kind, flags_out);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    DevBuf fl;
+    if (m->in_X.ensure((size_t)n_total * 12) || m->in_ids.ensure((size_t)n_total * KMAX * id_sz) || fl.ensure((size_t)n_total))
+        return fail(PESTO_ERR_NOMEM, "staging allocation failed");
+    hipError_t he = hipMemcpyAsync(m->in_X.p, X, (size_t)n_total * 12, hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(m->in_ids.p, ids, (size_t)n_total * KMAX * id_sz, hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) {
+        launch_knn_ties(st, (int)n_total, n_struct, m->knn_off.as<int>(), m->in_X.as<float>(), k, m->in_ids.p, ids_kind, fl.as<unsigned char>());
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(flags_out, fl.p, (size_t)n_total, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    fl.release();
+    if (he != hipSuccess) return fail(PESTO_ERR_HIP, "knn_tie_rows: %s", hipGetErrorString(he));
+    return 0;
+}
+
 int pesto_mask_to_segments(pesto_model* m, int64_t N, int64_t R, const float* M, int32_t* res_of_atom_out, int32_t ptr_kind, void* stream) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || R > N || !M || !res_of_atom_out) return fail(PESTO_ERR_INVALID, "bad arguments");

@@ -50,6 +50,9 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
 // results either way
 void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, void* ids_out, int ids_kind,
                         int use_grid, const int* slots, void* grids, int* cell_cnt, int* cell_cur, int* cell_of, void* sorted);
+// flags[i] bit c set: an exact distance tie of row i straddles the cut after column 8 << c of the table `ids` ([n_total, 64], 1-based)
+void launch_knn_ties(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, const void* ids, int ids_kind,
+                     unsigned char* flags);
 size_t knn_grid_struct_bytes();
 int knn_cell_min();
 int knn_cells_per_struct();

@@ -803,6 +803,46 @@ __device__ __forceinline__ unsigned long long knn_key(float rx, float ry, float 
     return ((unsigned long long)((masked << 31) | __float_as_uint(d)) << 32) | (unsigned)local_index;   // d >= 0: bit 31 is free
 }
 
+// Exact fp32 distance ties that STRADDLE a neighbourhood cut-off: the table orders equal distances by index, the reference's torch.topk
+// leaves their order undefined (src/data_encoding.py:98-99), so for such a row the two disagree on which of two equally distant atoms
+// belongs to the first 8 / 16 / 32 / 64 neighbours - the one difference between the tables that can move a logit (a tie inside a
+// neighbourhood only reorders a sum). One wave per row: the keys (masked flag | distance bits, as knn_key) of the table's last column
+// inside every cut, the number of columns inside the cut that carry that key, and - one scan over the atoms of the structure - the number
+// of atoms that do: more atoms than columns = the tie straddles the cut. flags[i]: bit 0 / 1 / 2 / 3 = cut after column 8 / 16 / 32 / 64.
+template <typename IdT>
+__global__ __launch_bounds__(256) void k_knn_ties(int n_total, int n_struct, const int* __restrict__ offsets, const float* __restrict__ X, int k,
+                                                  const IdT* __restrict__ ids, unsigned char* __restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_total) return;
+    const int s = knn_struct_of(i, n_struct, offsets);
+    const int s0 = offsets[s], s1 = offsets[s + 1];
+    const float xi = X[3 * (size_t)i], yi = X[3 * (size_t)i + 1], zi = X[3 * (size_t)i + 2];
+    auto dkey = [&](int j) -> unsigned {      // distance key of atom j (batch-global, 0-based): knn_key without the index
+        return (unsigned)(knn_key(X[3 * (size_t)j] - xi, X[3 * (size_t)j + 1] - yi, X[3 * (size_t)j + 2] - zi, 0) >> 32);
+    };
+    // this lane's column of the table (k <= 64 columns; 0 = padding)
+    const long long id = lane < k ? (long long)ids[(size_t)i * KMAX + lane] : 0;
+    const bool have = id > 0;
+    const unsigned mykey = have ? dkey((int)id - 1) : 0xffffffffu;
+    unsigned out = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cut = 8 << c;
+        if (cut > k) continue;
+        const long long id_last = ids[(size_t)i * KMAX + cut - 1];
+        if (id_last <= 0) continue;                                    // fewer than `cut` neighbours: nothing beyond the cut
+        const unsigned kc = __shfl(mykey, cut - 1);
+        const int inside = __popcll(__ballot(lane < cut && have && mykey == kc));
+        int all = 0;
+        for (int j = s0 + lane; j < s1; j += 64) all += dkey(j) == kc ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) all += __shfl_xor(all, o);
+        if (all > inside) out |= 1u << c;
+    }
+    if (lane == 0) flags[i] = (unsigned char)out;
+}
+
 template <typename IdT>
 __global__ __launch_bounds__(256) void k_knn_collate(int n_total, int n_struct, const int* __restrict__ offsets,
                                                      const float* __restrict__ X, int k, IdT* __restrict__ ids_out,
@@ -1035,5 +1075,12 @@ void launch_knn_collate(hipStream_t st, int n_total, int n_struct, const int* of
 size_t knn_grid_struct_bytes() { return sizeof(KnnGrid); }
 int knn_cell_min() { return KNN_CELL_MIN; }
 int knn_cells_per_struct() { return KNN_MAXC + 1; }
+
+void launch_knn_ties(hipStream_t st, int n_total, int n_struct, const int* offsets, const float* X, int k, const void* ids, int ids_kind,
+                      unsigned char* flags) {
+    const dim3 grid((n_total + 3) / 4), block(256);
+    if (ids_kind == PESTO_IDS_INT64) hipLaunchKernelGGL(k_knn_ties<long long>, grid, block, 0, st, n_total, n_struct, offsets, X, k, (const long long*)ids, flags);
+    else hipLaunchKernelGGL(k_knn_ties<int>, grid, block, 0, st, n_total, n_struct, offsets, X, k, (const int*)ids, flags);
+}
 
 }  // namespace pesto

@@ -576,6 +576,38 @@ class Model:
             return torch.from_numpy(ids)
         return ids
 
+    def knn_tie_rows(self, X, sizes, ids_topk, k=64):
+        """uint8 [sum(sizes)]: bit 0 / 1 / 2 / 3 set where an exact float32 distance tie of that row straddles the cut after column
+        8 / 16 / 32 / 64 of ``ids_topk`` (the table of knn_collate for the same X / sizes) - the rows on which the reference's torch.topk
+        may have picked the other of two equally distant atoms for a layer's neighbourhood (pesto_knn_tie_rows). numpy in, numpy out."""
+        h = self._ensure()
+        lib = _lib.load()
+        sizes = [int(v) for v in sizes]
+        offs = np.zeros(len(sizes) + 1, dtype=np.int32)
+        offs[1:] = np.cumsum(sizes)
+        n = int(offs[-1])
+        if _is_torch(X) and X.is_cuda:                # ROCm tensors: uint8 ROCm tensor on the current stream
+            import torch
+            Xc = X.detach().to(torch.float32).contiguous()
+            idc = ids_topk.detach()
+            idc = (idc if idc.dtype in (torch.int32, torch.int64) else idc.to(torch.int64)).contiguous()
+            if tuple(Xc.shape) != (n, 3) or tuple(idc.shape) != (n, 64):
+                raise ValueError(f"X must be [{n},3] and ids_topk [{n},64]")
+            fl = torch.empty((n,), dtype=torch.uint8, device=X.device)
+            _lib.check(lib.pesto_knn_tie_rows(h, n, len(sizes), offs.ctypes.data, Xc.data_ptr(), k, idc.data_ptr(),
+                                              _lib.IDS_INT64 if idc.dtype == torch.int64 else _lib.IDS_INT32, fl.data_ptr(), _lib.PTR_DEVICE,
+                                              torch.cuda.current_stream(X.device).cuda_stream))
+            return fl
+        Xn = np.ascontiguousarray(X.detach().cpu().numpy() if _is_torch(X) else X, dtype=np.float32)
+        idn = ids_topk.detach().cpu().numpy() if _is_torch(ids_topk) else np.asarray(ids_topk)
+        idn = np.ascontiguousarray(idn if idn.dtype in (np.int32, np.int64) else idn.astype(np.int64))
+        if Xn.shape != (n, 3) or idn.shape != (n, 64):
+            raise ValueError(f"X must be [{n},3] and ids_topk [{n},64]")
+        flags = np.zeros(n, np.uint8)
+        _lib.check(lib.pesto_knn_tie_rows(h, n, len(sizes), offs.ctypes.data, Xn.ctypes.data, k, idn.ctypes.data,
+                                          _lib.IDS_INT64 if idn.dtype == np.int64 else _lib.IDS_INT32, flags.ctypes.data, _lib.PTR_HOST, None))
+        return flags
+
     # ------------------------------------------------------------------ per-stage access (tests)
     def stage_embed(self, q0):
         q0 = np.ascontiguousarray(q0, np.float32)

@@ -41,11 +41,25 @@ def _norm_xyz(R):
     """float32 ||R|| over the last (xyz) axis exactly as torch.norm computes it in the reference's build: the scalar reduction
     acc = acc + v * v contracted into an FMA chain, sqrt(fma(z, z, fma(y, y, x * x))) - bit-identical to the reference's distance
     matrix on 555,000 pairs of a pdbs_test chain, where separately rounded products agree on 89 % only (and a one-ulp difference
-    reorders two neighbours in about one row of 40,000). The FMAs are emulated in float64: a product of two float32 is exact there."""
+    reorders two neighbours in about one row of 40,000). The FMAs are emulated in float64: a product of two float32 is exact there and the
+    sum is rounded once (_fma_round_f32)."""
     x, y, z = (R[..., c].astype(np.float64) for c in range(3))
     t = (x * x).astype(np.float32).astype(np.float64)
-    t = (t + y * y).astype(np.float32).astype(np.float64)
-    return np.sqrt((t + z * z).astype(np.float32))
+    t = _fma_round_f32(y * y, t).astype(np.float64)
+    return np.sqrt(_fma_round_f32(z * z, t))
+
+
+def _fma_round_f32(p, c):
+    """float32(p + c) with ONE rounding, p an exact float64 product of two float32, c a float32 held in float64: the float64 sum is
+    rounded to odd first (TwoSum residual != 0 and an even last bit -> the neighbour towards the residual), after which the rounding to
+    float32 cannot double-round - a plain float64 add followed by the cast can, when the sum falls exactly on a float32 tie."""
+    s = p + c
+    bb = s - p
+    e = (p - (s - bb)) + (c - bb)                     # exact residual of the float64 addition
+    even = (s.view(np.int64) & 1) == 0
+    nudge = (e != 0) & even & np.isfinite(s)
+    s = np.where(nudge, np.nextafter(s, np.where(e > 0, np.inf, -np.inf)), s)
+    return s.astype(np.float32)
 
 
 def _topology_dense(X, knn):

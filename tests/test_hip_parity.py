@@ -686,6 +686,61 @@ def test_config4_all_53_pdbs_test_chains(tag, zkey, qkey):
     print(f"config 4, 53 chains, {tag}: max |hip - reference| = {worst:.2e}")
 
 
+def test_drop_in_knn_path_on_all_53_chains_ties_are_reported():
+    """The DROP-IN path (GPU k-NN inside, no patched ids) on all 53 pdbs_test chains: the tables differ from the reference's only on rows
+    with two neighbours at exactly the same float32 distance (torch.topk's order there is undefined, src/data_encoding.py:98-99; here:
+    by index). pesto_knn_tie_rows reports the rows on which such a tie STRADDLES a neighbourhood cut-off - the only rows where the
+    difference can move a logit. Asserted: (1) the report equals a numpy statement of the same rule, entry for entry; (2) every row of
+    the fixture's patch list (where the reference's table differs) whose swap crosses a cut is reported for that cut; (3) every chain
+    whose logits deviate from the reference by more than 1e-4 has a reported row on a cut its model uses - all other chains are inside
+    the bound with the GPU table as it is."""
+    from conftest import cfg4_all53, golden as _g
+    from pesto_amd.topology import _norm_xyz
+    m = _model("i_v4_0", "mfma")
+    chains = cfg4_all53()
+    patches = _g("cfg4_all53")["tie_patches"]
+    structs, flagged, n_rows = [], [], 0
+    for ci, ch in enumerate(chains):
+        X = ch["X"]
+        n = X.shape[0]
+        ids = m.knn_collate(X, [n])                              # 1-based
+        assert np.array_equal(ids, ch["ids0_host"].astype(np.int64) + 1)
+        fl = m.knn_tie_rows(X, [n], ids)
+        # (1) numpy statement for this chain: distances of every atom pair as the library rounds them (FMA-chain norm)
+        if ci % 9 == 0:
+            D = _norm_xyz(X[None, :, :] - X[:, None, :])       # [i, j]
+            key = np.where(D < 1e-2, D + 1e9, D)                # masked entries sort behind every other atom, by D among themselves
+            want = np.zeros(n, np.uint8)
+            for c, cut in enumerate((8, 16, 32, 64)):
+                kc = key[np.arange(n), ids[:, cut - 1] - 1]
+                inside = (key[np.arange(n)[:, None], ids[:, :cut] - 1] == kc[:, None]).sum(1)
+                want |= ((key == kc[:, None]).sum(1) > inside).astype(np.uint8) << c
+            assert np.array_equal(fl, want), ch["name"]
+        # (2) the fixture's patch rows: a swap of slots (c - 1, c) with c a cut must be reported for that cut
+        rows = patches[patches[:, 0] == ci]
+        for r in np.unique(rows[:, 1]):
+            cols = sorted(int(v) for v in rows[rows[:, 1] == r][:, 2])
+            for b, cut in enumerate((8, 16, 32)):
+                if cut - 1 in cols and cut in cols:
+                    assert fl[r] & (1 << b), (ch["name"], int(r), cut)
+        flagged.append(fl)
+        n_rows += int((fl != 0).sum())
+        roa = ch["res_of_atom"]
+        M = np.zeros((roa.size, ch["R"]), np.float32)
+        M[np.arange(roa.size), roa] = 1.0
+        structs.append((X, (ids - 1).astype(np.int32), ch["q0"], M))
+    from pesto_amd.sharding import forward_local
+    out = forward_local(m, structs, list(range(len(structs))))
+    n_dev = 0
+    for ci, ch in enumerate(chains):
+        err = float(np.abs(out[ci] - ch["z_i_v4_0"]).max())
+        if err >= 1e-4:
+            n_dev += 1
+            assert (flagged[ci] & 0x0f).any(), (ch["name"], err)      # i_v4_0 uses nn = 8, 16, 32 and 64 (k = 64: the 64 / 65 tie changes the SET)
+    print(f"\n   drop-in k-NN path, 53 chains: {n_rows} of 132,417 rows reported (a tie straddles a cut), {n_dev} chain(s) beyond 1e-4, all of them reported")
+    assert n_rows < 200 and n_dev <= 3
+
+
 @pytest.mark.parametrize("tag,zkey,qkey", [("i_v4_0", "z_i_v4_0", "q0"), ("i_v3_0", "z_i_v3_0", "q0_all")])
 def test_example_complexes_with_nucleic_acids_lipids_ions(tag, zkey, qkey):
     """Seven multi-chain complexes of the reference's examples/ (DNA / RNA, lipids, ions, ligands next to protein chains; 955 - 15,635

@@ -238,3 +238,26 @@ def test_sharded_hip_forward_equals_single_process_bitwise(tmp_path, backend, wo
         assert len(got.files) == len(structures)
         for i in range(len(structures)):
             assert np.array_equal(got[str(i)], single[i]), (rank, i)
+
+
+@pytest.mark.gpu
+def test_bench_launcher_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver calls it (self-launch under torch.distributed.run), both ranks on GPU 0 with gloo: ONE JSON
+    line on stdout, whole-job value, per-rank values, and the config-4 leg (8 structures per rank) bitwise equal to a world-1 run."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-gpu", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--cpu-budget", "0", "--no-latency", "--config4-structures", "8"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert len(out["per_rank"]) == 2 and out["rank_time_max_over_min"] >= 1.0
+    c4 = out["config4_sharded"]
+    assert c4["structures"] == 16 and c4["bitwise_equal_to_world1"] is True and c4["parity_max_abs_vs_reference"] < 1e-4
+    assert len(c4["per_rank"]) == 2 and sum(r["structures"] for r in c4["per_rank"]) == 16
+    assert "cpu_baseline" not in out          # (rank 0 at N = 1 only)
