@@ -800,6 +800,36 @@ __device__ __forceinline__ L1Head l1_head(const L1Raw& r, int t, int lane, const
     return o;
 }
 
+// One-tile work items (ONEP): the p_j . r_hat operand of a tile is the same in both passes - the second pass reuses the (hi, lo) pair of
+// the first and only fetches what differs per feature-block half: the A_j chunks and the centre-record columns of blocks fb0 .. fb0 + 3.
+// Issued right behind the first pass's head, they land under the key networks and the softmax (a one-tile item has no next tile whose
+// loads it could overlap with: each of its dependent round trips is paid in full). Same values, same order: same bits as two passes.
+struct L1RawAC { f32x4 a4[4]; float cA[4], cB[4]; };
+template <int NN>
+__device__ __forceinline__ L1RawAC l1_issue_ac(int fb0, int lane, const TileCtx& tc) {
+    L1RawAC r;
+    const int pc = prod_piece(lane);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        r.a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * pc);
+        r.cA[fb] = tc.cenA[(fb0 + fb) * 64 + lane];
+        r.cB[fb] = NN == 8 ? tc.cenB[(fb0 + fb) * 64 + lane] : 0.0f;
+    }
+    return r;
+}
+template <int NN>
+__device__ __forceinline__ L1Head l1_head_ac(const L1RawAC& r, f16x8 fh, f16x8 fl, int lane, const TileCtx& tc) {
+    L1Head o;
+    o.fh = fh; o.fl = fl;
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        o.acc[fb] = MFMA(r.cA[fb], tc.bgA, to_mfma_lanes(r.a4[fb], lane));
+        if (NN == 8) o.acc[fb] = MFMA(r.cB[fb], tc.bgB, o.acc[fb]);
+    }
+    o.d = tc.d;
+    return o;
+}
+
 __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, const float* __restrict__ w1p, const float* __restrict__ wd,
                                         f32x4* h1, float& sat) {
 #pragma unroll
@@ -877,6 +907,20 @@ __device__ __forceinline__ float xhalf(float x) {
     float a = x, b;
     asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
     return IS_MAX ? fmaxf(a, b) : a + b;
+}
+// Reduce-scatter steps of the centre epilogue (EPI2): a and b are two accumulators that BOTH need the sum over a pair of lane rows
+// (16-lane rows r, r ^ 1) resp. lane halves. v_permlane16_swap exchanges the odd rows of a with the even rows of b - afterwards a + b is,
+// in the even rows, a's total over the row pair and, in the odd rows, b's: one swap + one add for two values (the ds_bpermute form:
+// two address computations, two permutes, two adds - and every lane ends with both totals although only one row of lanes stores them).
+// Same operands, commutative add: the same bits as x += shfl_xor(x, 16). Inline asm as xrow above (the builtin is unusable here);
+// the callers fence the block with sched_barrier so that no matrix instruction is in flight around it.
+__device__ __forceinline__ float swap_add_rows(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swap_add_halves(float a, float b) {      // lanes 0..31: a's total over (l, l + 32); lanes 32..63: b's
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
 }
 // reduction over the lanes of one centre inside a 32-lane half (16 lanes for nn = 16, the whole half otherwise)
 template <int NN, bool IS_MAX>
@@ -1545,6 +1589,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         PHASE_MARK(0);
 
         // ------------------------------------------------------------------ pass 1: keys -> logits (eqkm, epkm)
+        constexpr bool ONEP = TI == 1 && !PF && HY;      // one-tile items: see l1_issue_ac
+        L1RawAC rac2;
+        f16x8 pr_h, pr_l;
+        (void)rac2; (void)pr_h; (void)pr_l;
         {
             // layers 2/3 of the key networks for one tile, raw logits parked in the (not yet used) attention-weight table
             auto keys_of_tile = [&](int t, const f32x4* h1) {
@@ -1657,6 +1705,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         if (SAT2 && t == TI / 2) { const float tmp = sat; sat = sat_b; sat_b = tmp; }      // the second centre's tiles start
                         L1Head hd = l1_head<NN>(raw, t, lane, tcc, ws);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (ONEP) { rac2 = l1_issue_ac<NN>(4, lane, tcc); pr_h = hd.fh; pr_l = hd.fl; }
                         if (t < TI - 1) {
                             tcc = tile_ctx<NN, HY>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
                             raw = l1_issue<NN>(0, t + 1, lane, tcc, ws, p_state);
@@ -1747,21 +1796,36 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             for (int fbl = 0; fbl < 4; ++fbl) pre[fbl] = l1_fetch<NN>(4 + fbl, lane, g, tcn.cenA, tcn.cenB, tcn.recj);
         }
         float pi_pre[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // centre's own p_i (second block of Vp, :133), fetched a tile phase early
+        // EPI2 (the shipped kernels): the centre epilogue as a reduce-scatter over the lane groups on v_permlane swaps - every lane ends with
+        // the totals of ITS four Z elements (q and p[0..2] of feature 16 (g & 1) + e, head g >> 1; nn = 8: eight, centre g >> 1, both
+        // heads), completes them in registers and stores them once. The ds_bpermute form gave every lane all sixteen totals, parked them
+        // in LDS and completed them there (read - modify - write): ~250 instructions per centre against ~80.
+        constexpr bool EPI2 = FIN && F16 && !PF;
+        float pi3[3] = {0.f, 0.f, 0.f};                     // EPI2: p_i[c][16 (g & 1) + e] of this lane's centre
+        (void)pi3;
         for (int t = 0; t < TI; ++t) {
             const TileCtx tc = PF ? tcn : tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
             if (t % TPC == 0) {
+                if (EPI2) {
+                    const int ic = ABL_CEN(min(c0 + (NN == 8 ? 2 * t + (g >> 1) : (16 * t) / NN), N1 - 1));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) pi3[c] = p_state[(size_t)ic * 96 + c * 32 + 16 * (g & 1) + e];
+                } else {
 #pragma unroll
                 for (int sel = 0; sel < (NN == 8 ? 2 : 1); ++sel) {
                     const int ic = ABL_CEN(min(c0 + (NN == 8 ? 2 * t + sel : (16 * t) / NN), N1 - 1));
                     pi_pre[sel][0] = p_state[(size_t)ic * 96 + lane];
                     pi_pre[sel][1] = p_state[(size_t)ic * 96 + 64 + (lane & 31)];
                 }
+                }
             }
             // neighbours' p_j of this tile (third block of Vp, :134) as 16-byte gathers: lane = (esub = lane / 24, quad =
             // lane % 24) reads floats 4*quad..+3 of the 96-vector of edges 2i + esub; issued first, consumed after the
             // first-layer VALU work below
             // (lanes 48..63 duplicate lanes 0..15's addresses; their sums are never read - no divergent branch around the loads)
-            const int esub = lane / 24, quad = lane - 24 * esub;
+            // (EPI2: the two edge parities are the two lane halves - 24 of 32 lanes each carry a piece, the others repeat pieces 0..7 -
+            // so that the fold over the parities is a half swap)
+            const int esub = EPI2 ? lane >> 5 : lane / 24, quad = EPI2 ? ((lane & 31) < 24 ? (lane & 31) : (lane & 31) - 24) : lane - 24 * esub;
             f32x4 pv[4];
             {
                 int nbj[4];
@@ -1776,9 +1840,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 for (int fbl = 0; fbl < 4; ++fbl)
                     h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
             } else {
-                const L1Raw raw = l1_issue<NN>(4, t, lane, tc, ws, p_state);
-                __builtin_amdgcn_sched_barrier(0);
-                L1Head hd = l1_head<NN>(raw, t, lane, tc, ws);
+                L1Head hd;
+                if (ONEP) {
+                    hd = l1_head_ac<NN>(rac2, pr_h, pr_l, lane, tc);
+                } else {
+                    const L1Raw raw = l1_issue<NN>(4, t, lane, tc, ws, p_state);
+                    __builtin_amdgcn_sched_barrier(0);
+                    hd = l1_head<NN>(raw, t, lane, tc, ws);
+                }
                 __builtin_amdgcn_s_setprio(1);
                 l1_tail(hd, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
             }
@@ -1923,6 +1992,58 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 // only flag too many of the item's centres, never too few)
                 if (FIN) { sat = sat_b; sat_b = 0.0f; }
             }
+            if constexpr (EPI2) {
+                // ---- centre(s) complete (EPI2): reduce-scatter over the lane groups, finish in registers, one store per element
+                __builtin_amdgcn_sched_barrier(0);
+                float Qt[2], Pt[2][3];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {      // rows (g, g ^ 1): even rows end with the k = 0 totals, odd rows with the k = 1 totals
+                    Qt[h] = swap_add_rows(zq[h][0], zq[h][1]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Pt[h][c] = swap_add_rows(zp1[h][c][0], zp1[h][c][1]);
+                }
+                if (NN >= 16) {                    // halves: lanes 0..31 end with head 0, lanes 32..63 with head 1 (nn = 8: the halves are two centres)
+                    Qt[0] = swap_add_halves(Qt[0], Qt[1]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Pt[0][c] = swap_add_halves(Pt[0][c], Pt[1][c]);
+                }
+                {   // p_j sums: fold the two edge parities (lane halves): lanes 0..31 end with head 0, lanes 32..63 with head 1
+                    f32x4 za, zb4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        za[j] = swap_add_halves(z3a[0][j], z3a[1][j]);
+                        if (NN == 8) zb4[j] = swap_add_halves(z3b[0][j], z3b[1][j]);
+                    }
+                    if ((lane & 31) < 24) {
+                        st4(&ws.z3buf[0][lane >> 5][4 * (lane & 31)], za);
+                        if (NN == 8) st4(&ws.z3buf[1][lane >> 5][4 * (lane & 31)], zb4);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { z3a[h] = f32x4{0, 0, 0, 0}; z3b[h] = f32x4{0, 0, 0, 0}; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int s_l = 16 * (g & 1) + e;                                        // this lane's feature
+                if (NN >= 16) {
+                    const int slot0 = SUBS > 1 ? sub : (16 * t) / NN;                    // FIN keeps every centre of the iteration staged
+                    const int a = (16 * t) / NN, hh = g >> 1;
+                    float* zb = zrow[slot0];
+                    const float wsm = ws.wsum[a][hh];
+                    zb[hh * 32 + s_l] = Qt[0];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) zb[64 + c * 64 + hh * 32 + s_l] = Pt[0][c] + (wsm * pi3[c] + ws.z3buf[0][hh][c * 32 + s_l]);
+                } else {
+                    const int sel = g >> 1, a = 2 * t + sel;
+                    float* zb = zrow[sel];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float wsm = ws.wsum[a][h];
+                        zb[h * 32 + s_l] = Qt[h];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) zb[64 + c * 64 + h * 32 + s_l] = Pt[h][c] + (wsm * pi3[c] + ws.z3buf[sel][h][c * 32 + s_l]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
             // ---- centre(s) complete: reduce the per-lane partial sums across lane groups, stage in LDS
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -1996,6 +2117,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                             zo[64 + 128 + h * 32 + lane] = zb[64 + 128 + h * 32 + lane] + ws.wsum[a][h] * pi1 + ws.z3buf[sel][h][64 + lane];
                     }
                 }
+            }
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h)
