@@ -1590,6 +1590,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 
         // ------------------------------------------------------------------ pass 1: keys -> logits (eqkm, epkm)
         constexpr bool ONEP = TI == 1 && !PF && HY;      // one-tile items: see l1_issue_ac
+        // W3SPLIT: the part-3 attention weights (the p_j sums' weights) are kept parity-split in LDS and read 16 bytes at a time. Not in the
+        // fine-item nn = 32 instantiation (one-structure launches): at the 168-register limit the two live float4 spill there (20 B per
+        // lane, +0.7 us per launch, measured in both pairs of profiles/r04_epilogue_ab.txt). Writer and reader share this switch.
+        constexpr bool W3SPLIT = !(FIN && NN == 32 && TI == 2);
         L1RawAC rac2;
         f16x8 pr_h, pr_l;
         (void)rac2; (void)pr_h; (void)pr_l;
@@ -1770,7 +1774,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     s3 = e < 8 ? lane_bcast(sm_, 48) : lane_bcast(sm_, 56);
                 }
                 const float tot = g == 0 ? sm_ : (s1 + s2) + s3;
-                ws.wts[h * 4 + g][16 * t + e] = ex[t] * __builtin_amdgcn_rcpf(tot);
+                // the part-3 rows (g == 3: the weights of the p_j sums) are stored parity-split within the tile - [edges 0, 2, .. 14 | 1, 3, .. 15] -
+                // because their only reader takes the edges of ONE parity: two 16-byte reads per row and tile instead of eight 4-byte ones
+                ws.wts[h * 4 + g][16 * t + ((W3SPLIT && g == 3) ? ((e & 1) << 3) + (e >> 1) : e)] = ex[t] * __builtin_amdgcn_rcpf(tot);
                 // centre-level sum of the part-2 weights (what multiplies p_i in Zp): written by the part-2 lanes
                 if (g == 2 && (NN == 8 ? (e & 7) == 0 : e == 0) && (t % TPC) == 0) {
                     const int a = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
@@ -1852,11 +1858,17 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 l1_tail(hd, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (W3SPLIT) {
+                const f32x4 w0 = ld4(&ws.wts[3][16 * t + 8 * (esub & 1)]), w1 = ld4(&ws.wts[7][16 * t + 8 * (esub & 1)]);      // edges 2 i2 + parity, i2 = 0..3
 #pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {
-                const int ee = 2 * i2 + (esub & 1);
-                const float w0 = ws.wts[3][16 * t + ee], w1 = ws.wts[7][16 * t + ee];
-                z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2];
+                for (int i2 = 0; i2 < 4; ++i2) { z3a[0] += w0[i2] * pv[i2]; z3a[1] += w1[i2] * pv[i2]; }
+            } else {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    const int ee = 2 * i2 + (esub & 1);
+                    const float w0 = ws.wts[3][16 * t + ee], w1 = ws.wts[7][16 * t + ee];
+                    z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2];
+                }
             }
             // the first-layer operands of the NEXT tile fly during this tile's MFMA phase
             if (PF && t < 3) {
@@ -1957,12 +1969,20 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             }
             PHASE_MARK(4);
             __builtin_amdgcn_s_setprio(0);
+            if constexpr (W3SPLIT) {
+                const f32x4 w0 = ld4(&ws.wts[3][16 * t + 8 * (esub & 1) + 4]), w1 = ld4(&ws.wts[7][16 * t + 8 * (esub & 1) + 4]);   // edges 8 + 2 i2 + parity
 #pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {
-                const int ee = 8 + 2 * i2 + (esub & 1);
-                const float w0 = ws.wts[3][16 * t + ee], w1 = ws.wts[7][16 * t + ee];
-                if (NN == 8) { z3b[0] += w0 * pv[i2]; z3b[1] += w1 * pv[i2]; }
-                else { z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2]; }
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    if (NN == 8) { z3b[0] += w0[i2] * pv[i2]; z3b[1] += w1[i2] * pv[i2]; }
+                    else { z3a[0] += w0[i2] * pv[i2]; z3a[1] += w1[i2] * pv[i2]; }
+                }
+            } else {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    const int ee = 8 + 2 * i2 + (esub & 1);
+                    const float w0 = ws.wts[3][16 * t + ee], w1 = ws.wts[7][16 * t + ee];
+                    z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2];      // (NN == 32 here)
+                }
             }
             // attention-weighted sums over this lane's four edges (:143-144, first block of Vp :132)
             const int r0 = 16 * t + 4 * g;
