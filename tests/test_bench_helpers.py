@@ -35,15 +35,6 @@ def test_config4_histogram_is_the_reference_set():
     assert max(loads) - min(loads) < 1641 and all(len(p) == 8 for p in parts)                # 8 GPUs: balanced to one small chain
 
 
-def test_traffic_file_is_stamped():
-    path = os.path.join(ROOT, "profiles", "traffic_i_v4_1_n3000_b8.json")
-    t = json.load(open(path))
-    assert len(t["source_hash"]) == 16 and any("k_edge<64" in k for k in t["kernel_symbols"])
-    assert len(bench.source_hash()) == 16            # (whether it matches the tree decides if bench.py quotes the file)
-    per = [v for k, v in t["kernels"].items() if "k_edge<64" in k][0]
-    assert per["dispatches_per_forward"] == 8 and per["write_bytes_per_dispatch"] > 0
-
-
 def test_per_nn_table_and_rocprof_fraction():
     """bench.py's per-kernel table: every layer kernel of the forward with its def-A fraction by HIP events and - only when the committed
     profile carries the source hash of the build - by the rocprofv3 trace, its HBM-side traffic and traffic / compulsory bytes."""
