@@ -1,3 +1,6 @@
+    // measured alternative (round 5, -DPESTO_ELU_MAX): c ELU(x) = max(t, c min(2^t, 1) - c) with the clamp as v_exp_f32's output modifier and one
+    // VOP2 v_max_f32 instead of the VOP3 v_med3_f32 - cheaper by the price list of r03_valu_cost.txt, SLOWER in the kernel (same box:
+    // nn = 64 260.4 -> 263.4 us, nn = 32 147.0 -> 149.2; the clamp forces the 64-bit encoding of v_exp_f32 and moves the schedule)
 // pesto_layer_mfma.hip - the state-update layer on the gfx950 matrix cores.
 //
 // Reference math: src/model_operations.py:87-154 (StateUpdate.forward) + :225-242 (StateUpdateLayer.forward).
@@ -131,10 +134,21 @@ __device__ __forceinline__ f32x4 elu4s(f32x4 t) {
     return f32x4{fmaxf(t[0], -1.4426950f), fmaxf(t[1], -1.4426950f), fmaxf(t[2], -1.4426950f), fmaxf(t[3], -1.4426950f)};
 #endif
     constexpr float C = 1.44269504088896340736f;
+#ifndef PESTO_ELU_MAX      // shipped: exp, packed fma, v_med3_f32
     f32x4 ex = f32x4{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
     ex = ex * C - C;
     return f32x4{__builtin_amdgcn_fmed3f(t[0], ex[0], 0.0f), __builtin_amdgcn_fmed3f(t[1], ex[1], 0.0f),
                  __builtin_amdgcn_fmed3f(t[2], ex[2], 0.0f), __builtin_amdgcn_fmed3f(t[3], ex[3], 0.0f)};
+#else
+    // measured alternative (round 5, -DPESTO_ELU_MAX): c ELU(x) = max(t, c min(2^t, 1) - c), the clamp as v_exp_f32's output modifier and one
+    // VOP2 v_max_f32 instead of the VOP3 v_med3_f32 - cheaper by the price list of profiles/microbench/r03_valu_cost.txt, SLOWER in the
+    // kernel (same box: nn = 64 260.4 -> 263.4 us, nn = 32 147.0 -> 149.2; the clamp forces the 64-bit encoding of v_exp_f32 and the
+    // schedule moves). Same value except for 0 < t < 2^-24, where 2^t rounds to 1: med3(t, 0, 0) = 0, this form returns t.
+    f32x4 ex = f32x4{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(t[0]), 0.0f, 1.0f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(t[1]), 0.0f, 1.0f),
+                     __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(t[2]), 0.0f, 1.0f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(t[3]), 0.0f, 1.0f)};
+    ex = ex * C - C;
+    return f32x4{__builtin_fmaxf(t[0], ex[0]), __builtin_fmaxf(t[1], ex[1]), __builtin_fmaxf(t[2], ex[2]), __builtin_fmaxf(t[3], ex[3])};
+#endif
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -147,6 +161,13 @@ __device__ __forceinline__ void st4_finite(float* p, f32x4 v) {
     st4(p, f32x4{__builtin_amdgcn_fmed3f(v[0], -M, M), __builtin_amdgcn_fmed3f(v[1], -M, M), __builtin_amdgcn_fmed3f(v[2], -M, M),
                  __builtin_amdgcn_fmed3f(v[3], -M, M)});
 }
+
+// ||p|| over xyz of the f16-split path's node inputs (model_operations.py:105): the bare v_sqrt_f32 (1 ulp). sqrtf() is correctly rounded and
+// expands to ~17 VALU per value (scaling of denormal inputs, two Newton corrections, class checks); every node wave / finishing role evaluates
+// eight norms per lane for each 16-centre tile - in node-wave mode that was 540 wave-instructions per 16 centres (68 per nn = 8 tile).
+// One ulp of ||p|| is 6e-8 relative on an input that is split to 2^-22 anyway. k_node16 and both in-kernel prepare phases share this
+// function: their records stay bit-identical to each other. (The exact fp32 kernels keep sqrtf.)
+__device__ __forceinline__ float norm3_fast(float x, float y, float z) { return __builtin_amdgcn_sqrtf(x * x + y * y + z * z); }
 
 // acc[m] += W[m-block][fb-block] * x for the four k-steps r of block fb; frag table [m][fb][lane][r] in `wf`
 template <int NFB>
@@ -468,7 +489,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                pn[m][r] = sqrtf(p[0][m][r] * p[0][m][r] + p[1][m][r] * p[1][m][r] + p[2][m][r] * p[2][m][r]);
+                pn[m][r] = norm3_fast(p[0][m][r], p[1][m][r], p[2][m][r]);
         f16x8 xnh[2], xnl[2], ph[3], pl[3];
         split8(q[0], q[1], xnh[0], xnl[0]);
         split8(pn[0], pn[1], xnh[1], xnl[1]);
@@ -529,7 +550,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
             split8(elu4(h[0]), elu4(h[1]), xh, xl);
             mfma16_multi<2>(Lnq + 2048, 0, 1, 0, lane, xh, xl, t);
             sat_probe(sat, t[0][0]);
-            f32x4 qq[1] = {ld4(W + wp_.n_bn2 + 4 * g)};
+            f32x4 qq[1] = {ld4(W + wp_.n_bn2s + 4 * g)};
             split8(elu4(t[0]), elu4(t[1]), xh, xl);
             mfma16_multi<1>(Lnq + 3072, 0, 1, 0, lane, xh, xl, qq);
             sat_probe(sat, qq[0][0]);
@@ -655,6 +676,9 @@ struct EdgeSmem {
     typename std::conditional<M32, EdgeWaveScratch32, EdgeWaveScratch>::type ws[NE];
     float zrows[NE][GEN][2][256];   // Zq | Zp staging per centre: two rows per edge wave (and generation)
     float xch[XCH ? (NE < WPB ? 2 * 2048 : XCH_FLOATS) : 4];
+    // bias of the value network's last layer, four copies per feature: the accumulator tile of feature column e starts as (b, b, b, b) -
+    // one ds_read_b128 instead of a 4-byte read + four v_mov per block (16 v_mov per tile). Filled by the kernel's prologue.
+    alignas(16) float b3v4[(HY && !M32) ? 256 : 4];
     int xflag[8];        // monotone counters (see XF_*)
 };
 // poll an LDS counter of this workgroup (all its waves are resident); SLEEP x 64 cycles between two looks: a polling wave takes issue
@@ -1486,6 +1510,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
         for (int k = threadIdx.x; k < (M32 ? EDGE_LDS_FLOATS_32 : HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS) / 4; k += WPB * 64) dst[k] = src[k];
     }
+    if constexpr (HY && !M32) {
+        if (threadIdx.x < 64) {
+            const float b = W[lw.e_lds16 + EL_B3V + threadIdx.x];
+            st4(&sm.b3v4[4 * threadIdx.x], f32x4{b, b, b, b});
+        }
+    }
     if constexpr (!M32) {
         if (first_item) {     // rows of the first item -> the wave's scratch (no register survives into the work loop)
             auto& ws0 = sm.ws[threadIdx.x >> 6];
@@ -1555,7 +1585,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             __builtin_amdgcn_wave_barrier();
             PHASE_INIT();
             TRACE32(20);
-            edge_item32<NN, TI / 2>(ws, sm.w, zrow, sub, lane, c0, N1, make_rsrc(rec_nb), make_rsrc(rec_cen), make_rsrc(p_state), inv_sdk, sat, tr_n);
+            edge_item32<NN, TI / 2>(ws, sm.w, zrow, sub, lane, c0, N1, make_rsrc(rec_nb), make_rsrc(rec_cen), make_rsrc(p_state), 0.69314718055994530942f /* Q' = Q log2(e) / sdk: ln 2 gives logit / sdk back */, sat, tr_n);
             // (developer variant: a lane's probes cover every centre of the item - all of them are flagged)
 #pragma unroll
             for (int a = 0; a < A; ++a) if (c0 + a < N1) sat_flush_at(sat, flags, c0 + a);
@@ -1671,7 +1701,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 const float* Qv = rec_cen + (size_t)ABL_CEN(min(c0 + aMine, N1 - 1)) * REC_CEN + 512 + (g == 0 ? 0 : 6);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    ws.wts[h * 4 + g][16 * t + e] = (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) * inv_sdk;
+                    ws.wts[h * 4 + g][16 * t + e] = F16 ? Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]      // t = log2(e) logit / sdk: Q' carries the scale
+                                                        : (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) * inv_sdk;
             };
             if (PF) {
                 // tile-batched: the four first-layer blocks of a tile are computed together (VALU phase, independent
@@ -1733,54 +1764,99 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         PHASE_MARK(1);
         // ------------------------------------------------------------------ softmax per centre  (:139-140)
         // scalar: over the NN rows of part 0; vector: over the 3*NN slots of parts 1..3 together
+        if constexpr (F16) {
+            // Split path: w = exp2(t) / sum exp2(t), t = log2(e) logit / sdk (the scale rides on Q', pesto_schema.cpp) - torch's softmax
+            // (:139-140) subtracts the row maximum first, which is the same function and only protects the exponent range. Here the
+            // range is GUARDED instead of protected: the logits of the trained checkpoints stay within -39 .. +64
+            // (profiles/r05_logit_range.txt; fp32 holds e^+-87), and a centre whose sum leaves [2^-101, inf) - overflow, or every
+            // term flushed - trips the range guard of its structure (sat_probe), which PESTO_PRECISION_AUTO repeats on the exact fp32
+            // kernels (they keep the max-subtracted form below). Per head and centre that removes a 16-lane max reduction, three
+            // readlanes and the subtraction; the cross-part sum of the vector softmax is two v_permlane swaps instead of three
+            // v_readlane + moves (nn = 8: six, selected per lane half), and the centre's part-2 share is a multiply by the reciprocal
+            // the weights use anyway (it was an IEEE division: ten instructions).
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float mx[4], ex[4], sr[4];
+            for (int h = 0; h < 2; ++h) {
+                float ex[4], sr[4];
 #pragma unroll
-            for (int t = 0; t < TI; ++t) mx[t] = lg[t][h];
-            if (TPC == 4) { const float m = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])); mx[0] = mx[1] = mx[2] = mx[3] = m; }
-            if (TPC == 2) {
-                const float m0 = fmaxf(mx[0], mx[1]); mx[0] = mx[1] = m0;
-                if (TI == 4) { const float m1 = fmaxf(mx[2], mx[3]); mx[2] = mx[3] = m1; }
-            }
-#pragma unroll
-            for (int t = 0; t < TI; ++t) {
-                const float m = row_reduce<(NN >= 16), true>(mx[t]);
-                // rows 1..3 (the three vector-key chunks) share one softmax: fetch their row results (wave-uniform lanes)
-                float v1, v2, v3;
-                if (NN >= 16) { v1 = lane_bcast(m, 16); v2 = lane_bcast(m, 32); v3 = lane_bcast(m, 48); }
-                else {
-                    v1 = e < 8 ? lane_bcast(m, 16) : lane_bcast(m, 24);
-                    v2 = e < 8 ? lane_bcast(m, 32) : lane_bcast(m, 40);
-                    v3 = e < 8 ? lane_bcast(m, 48) : lane_bcast(m, 56);
+                for (int t = 0; t < TI; ++t) { ex[t] = __builtin_amdgcn_exp2f(lg[t][h]); sr[t] = ex[t]; }
+                if (TPC == 4) sr[0] = (sr[0] + sr[1]) + (sr[2] + sr[3]);
+                if (TPC == 2) {
+                    sr[0] = sr[0] + sr[1];
+                    if (TI == 4) sr[2] = sr[2] + sr[3];
                 }
-                mx[t] = g == 0 ? m : fmaxf(v1, fmaxf(v2, v3));
-                ex[t] = __expf(lg[t][h] - mx[t]);
-                sr[t] = ex[t];
-            }
-            if (TPC == 4) { const float s = (sr[0] + sr[1]) + (sr[2] + sr[3]); sr[0] = sr[1] = sr[2] = sr[3] = s; }
-            if (TPC == 2) {
-                const float s0 = sr[0] + sr[1]; sr[0] = sr[1] = s0;
-                if (TI == 4) { const float s1 = sr[2] + sr[3]; sr[2] = sr[3] = s1; }
-            }
 #pragma unroll
-            for (int t = 0; t < TI; ++t) {
-                const float sm_ = row_reduce<(NN >= 16), false>(sr[t]);
-                float s1, s2, s3;
-                if (NN >= 16) { s1 = lane_bcast(sm_, 16); s2 = lane_bcast(sm_, 32); s3 = lane_bcast(sm_, 48); }
-                else {
-                    s1 = e < 8 ? lane_bcast(sm_, 16) : lane_bcast(sm_, 24);
-                    s2 = e < 8 ? lane_bcast(sm_, 32) : lane_bcast(sm_, 40);
-                    s3 = e < 8 ? lane_bcast(sm_, 48) : lane_bcast(sm_, 56);
+                for (int t = 0; t < TI; t += TPC) {      // one centre per step (nn = 8: the tile's two centres in the two halves of every lane row)
+                    const float srow = row_reduce<(NN >= 16), false>(sr[t]);                 // this part's sum over the centre's edges
+                    const float tot_v = xrow<false>(xhalf<false>(g == 0 ? 0.0f : srow));     // parts 1..3 together (every lane row gets it)
+                    const float tot = g == 0 ? srow : tot_v;
+                    const float rinv = __builtin_amdgcn_rcpf(tot);
+                    float& sg = (SAT2 && t >= TI / 2) ? sat_b : sat;
+                    sat_probe(sg, tot);                     // sum overflowed (some logit > ~88)
+                    sat_probe(sg, rinv * 0x1p27f);          // sum below 2^-101: every term underflowed
+#pragma unroll
+                    for (int tt = t; tt < t + TPC; ++tt)
+                        // the part-3 rows (g == 3: the weights of the p_j sums) are stored parity-split within the tile - [edges 0, 2, .. 14 | 1, 3, .. 15] -
+                        // because their only reader takes the edges of ONE parity: two 16-byte reads per row and tile instead of eight 4-byte ones
+                        ws.wts[h * 4 + g][16 * tt + ((W3SPLIT && g == 3) ? ((e & 1) << 3) + (e >> 1) : e)] = ex[tt] * rinv;
+                    // centre-level sum of the part-2 weights (what multiplies p_i in Zp): written by the part-2 lanes
+                    if (g == 2 && (NN == 8 ? (e & 7) == 0 : e == 0)) {
+                        const int a = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
+                        ws.wsum[a][h] = srow * rinv;
+                    }
                 }
-                const float tot = g == 0 ? sm_ : (s1 + s2) + s3;
-                // the part-3 rows (g == 3: the weights of the p_j sums) are stored parity-split within the tile - [edges 0, 2, .. 14 | 1, 3, .. 15] -
-                // because their only reader takes the edges of ONE parity: two 16-byte reads per row and tile instead of eight 4-byte ones
-                ws.wts[h * 4 + g][16 * t + ((W3SPLIT && g == 3) ? ((e & 1) << 3) + (e >> 1) : e)] = ex[t] * __builtin_amdgcn_rcpf(tot);
-                // centre-level sum of the part-2 weights (what multiplies p_i in Zp): written by the part-2 lanes
-                if (g == 2 && (NN == 8 ? (e & 7) == 0 : e == 0) && (t % TPC) == 0) {
-                    const int a = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
-                    ws.wsum[a][h] = s2 / ((s1 + s2) + s3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float mx[4], ex[4], sr[4];
+#pragma unroll
+                for (int t = 0; t < TI; ++t) mx[t] = lg[t][h];
+                if (TPC == 4) { const float m = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])); mx[0] = mx[1] = mx[2] = mx[3] = m; }
+                if (TPC == 2) {
+                    const float m0 = fmaxf(mx[0], mx[1]); mx[0] = mx[1] = m0;
+                    if (TI == 4) { const float m1 = fmaxf(mx[2], mx[3]); mx[2] = mx[3] = m1; }
+                }
+#pragma unroll
+                for (int t = 0; t < TI; ++t) {
+                    const float m = row_reduce<(NN >= 16), true>(mx[t]);
+                    // rows 1..3 (the three vector-key chunks) share one softmax: fetch their row results (wave-uniform lanes)
+                    float v1, v2, v3;
+                    if (NN >= 16) { v1 = lane_bcast(m, 16); v2 = lane_bcast(m, 32); v3 = lane_bcast(m, 48); }
+                    else {
+                        v1 = e < 8 ? lane_bcast(m, 16) : lane_bcast(m, 24);
+                        v2 = e < 8 ? lane_bcast(m, 32) : lane_bcast(m, 40);
+                        v3 = e < 8 ? lane_bcast(m, 48) : lane_bcast(m, 56);
+                    }
+                    mx[t] = g == 0 ? m : fmaxf(v1, fmaxf(v2, v3));
+                    ex[t] = __expf(lg[t][h] - mx[t]);
+                    sr[t] = ex[t];
+                }
+                if (TPC == 4) { const float s = (sr[0] + sr[1]) + (sr[2] + sr[3]); sr[0] = sr[1] = sr[2] = sr[3] = s; }
+                if (TPC == 2) {
+                    const float s0 = sr[0] + sr[1]; sr[0] = sr[1] = s0;
+                    if (TI == 4) { const float s1 = sr[2] + sr[3]; sr[2] = sr[3] = s1; }
+                }
+#pragma unroll
+                for (int t = 0; t < TI; ++t) {
+                    const float sm_ = row_reduce<(NN >= 16), false>(sr[t]);
+                    float s1, s2, s3;
+                    if (NN >= 16) { s1 = lane_bcast(sm_, 16); s2 = lane_bcast(sm_, 32); s3 = lane_bcast(sm_, 48); }
+                    else {
+                        s1 = e < 8 ? lane_bcast(sm_, 16) : lane_bcast(sm_, 24);
+                        s2 = e < 8 ? lane_bcast(sm_, 32) : lane_bcast(sm_, 40);
+                        s3 = e < 8 ? lane_bcast(sm_, 48) : lane_bcast(sm_, 56);
+                    }
+                    const float tot = g == 0 ? sm_ : (s1 + s2) + s3;
+                    // the part-3 rows (g == 3: the weights of the p_j sums) are stored parity-split within the tile - [edges 0, 2, .. 14 | 1, 3, .. 15] -
+                    // because their only reader takes the edges of ONE parity: two 16-byte reads per row and tile instead of eight 4-byte ones
+                    ws.wts[h * 4 + g][16 * t + ((W3SPLIT && g == 3) ? ((e & 1) << 3) + (e >> 1) : e)] = ex[t] * __builtin_amdgcn_rcpf(tot);
+                    // centre-level sum of the part-2 weights (what multiplies p_i in Zp): written by the part-2 lanes
+                    if (g == 2 && (NN == 8 ? (e & 7) == 0 : e == 0) && (t % TPC) == 0) {
+                        const int a = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
+                        ws.wsum[a][h] = s2 / ((s1 + s2) + s3);
+                    }
                 }
             }
         }
@@ -1930,8 +2006,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             f32x4 v[4];
 #pragma unroll
             for (int fo = 0; fo < 4; ++fo) {
-                const float b = sm.w[EL_B3V + 16 * fo + e];
-                v[fo] = f32x4{b, b, b, b};
+                if constexpr (HY && !M32) {
+                    v[fo] = ld4(&sm.b3v4[4 * (16 * fo + e)]);
+                } else {
+                    const float b = sm.w[EL_B3V + 16 * fo + e];
+                    v[fo] = f32x4{b, b, b, b};
+                }
             }
             if (F16) {
 #pragma unroll
@@ -2216,7 +2296,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 for (int c = 0; c < 3; ++c) p3[c] = ld4(xs + ((2 + 2 * c + m) * 4 + fg) * ncol * 4 + fe * 4);
                 if (!xv) { q[m] = f32x4{0, 0, 0, 0}; p3[0] = q[m]; p3[1] = q[m]; p3[2] = q[m]; }    // (columns past the tile: not stored)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pn[m][r] = sqrtf(p3[0][r] * p3[0][r] + p3[1][r] * p3[1][r] + p3[2][r] * p3[2][r]);
+                for (int r = 0; r < 4; ++r) pn[m][r] = norm3_fast(p3[0][r], p3[1][r], p3[2][r]);
             }
             split8(q[0], q[1], xnh[0], xnl[0]);
             split8(pn[0], pn[1], xnh[1], xnl[1]);
@@ -2590,7 +2670,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                         for (int c = 0; c < 3; ++c) p3[c] = ld4(xs + ((2 + 2 * c + m) * 4 + fg) * 64 + fe * 4);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pn[m][r] = sqrtf(p3[0][r] * p3[0][r] + p3[1][r] * p3[1][r] + p3[2][r] * p3[2][r]);
+                        for (int r = 0; r < 4; ++r) pn[m][r] = norm3_fast(p3[0][r], p3[1][r], p3[2][r]);
                     }
                     split8(q[0], q[1], xnh[0], xnl[0]);
                     split8(pn[0], pn[1], xnh[1], xnl[1]);
@@ -2816,7 +2896,7 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags,
                  const float* q_state, float* q_out, float* p_out, const LayerW* next, float* rec_nb_out, float* rec_cen_out, int mode) {
     PrepW pw{};
-    if (next) pw = PrepW{next->h_ua, next->h_gc, next->h_n0, next->n_b1s, next->n_bn0, next->n_bn1, next->n_bn2};
+    if (next) pw = PrepW{next->h_ua, next->h_gc, next->h_n0, next->n_b1s, next->n_bn0, next->n_bn1, next->n_bn2s};      // (the split path's queries carry the softmax scale)
     const EdgeIO io{ids_s, geo, rec_nb, rec_cen, p_state, Z, flags, q_state, q_out, p_out, pw, next ? rec_nb_out : nullptr, next ? rec_cen_out : nullptr};
     // small launches (one structure, or the nn = 8/16 layers of a small batch) cannot fill 256 twelve-wave workgroups:
     // the same kernel body in smaller workgroups spreads them over more CUs

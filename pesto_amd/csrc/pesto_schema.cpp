@@ -1,6 +1,7 @@
 // pesto_schema.cpp - host blob schema and device weight image construction (host code only).
 #include "pesto_schema.h"
 
+#include <cmath>
 #include <cstring>
 
 namespace pesto {
@@ -361,7 +362,15 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
             put_block(N0, 0, 0, blob, L.nqm.l[0], 0, 64);
             put_block(N1, 0, 0, blob, L.nqm.l[1], 0, 32);
             put_block(N2, 0, 0, blob, L.nqm.l[2], 0, 32);
-            W.h_n0 = put_frags_f16(img, N0, 2, 2); W.h_n1 = put_frags_f16(img, N1, 2, 1); W.h_n2 = put_frags_f16(img, N2, 1, 1);
+            // The split path's node queries carry the softmax scale: Q' = Q log2(e) / sdk (sdk = sqrt(Nk), model_operations.py:85,139-140), so
+            // a logit Q'.K arrives as t = log2(e) x and the kernel's softmax is exp2(t) / sum exp2(t) - no per-edge multiply, a bare v_exp_f32.
+            const float QS = LOG2E * (1.0f / std::sqrt((float)NK));
+            W.h_n0 = put_frags_f16(img, N0, 2, 2); W.h_n1 = put_frags_f16(img, N1, 2, 1); W.h_n2 = put_frags_f16(img, N2.scaled(QS), 1, 1);
+            {
+                std::vector<float> bn2s(16, 0.0f);
+                for (int r = 0; r < 12; ++r) bn2s[r] = blob[L.nqm.l[2].b + r] * QS;
+                W.n_bn2s = put_vec(img, bn2s.data(), 16);
+            }
             W.n_n0 = put_frags(img, N0, 2, 4); W.n_bn0 = put_vec(img, blob + L.nqm.l[0].b, 32);
             W.n_n1 = put_frags(img, N1, 2, 2); W.n_bn1 = put_vec(img, blob + L.nqm.l[1].b, 32);
             W.n_n2 = put_frags(img, N2, 1, 2); W.n_bn2 = put_vec(img, blob + L.nqm.l[2].b, 12, 16);

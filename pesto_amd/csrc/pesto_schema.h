@@ -44,6 +44,7 @@ struct LayerW {
     int32_t n_q0, n_bq0, n_q1, n_bq1, n_q2, n_bq2, n_pp;   // qpm frags [2][4],[2][2],[2][2] + biases[32]; ppm frags [2][4]
     int32_t n_ua, n_b1, n_gc;                               // [U|A] frags [16][4], b1[128]; [G|C] frags [16][2]
     int32_t n_b1s;                                          // b1 x log2(e): bias of U on the f16-split path (log2-domain ELU, pesto_schema.cpp)
+    int32_t n_bn2s;                                         // nqm's last bias x log2(e) / sdk: the split path's queries carry the softmax scale (pesto_schema.cpp)
     int32_t n_n0, n_bn0, n_n1, n_bn1, n_n2, n_bn2;          // nqm frags [2][4],[2][2],[1][2] + biases (last padded to 16)
     // f16 hi/lo fragment tables of the same matrices (layout of put_frags_f16: [m][kgroup][hi|lo][lane][8 halves])
     int32_t h_q0, h_q1, h_q2, h_pp, h_ua, h_gc, h_n0, h_n1, h_n2;
