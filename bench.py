@@ -187,12 +187,16 @@ def cpu_baseline(config, sd, n_atoms, budget_s, config_key):
     return out
 
 
-def config4_structures(n_structures, model=None):
+def config4_structures(n_structures, model=None, forms="compact"):
     """The work list of BASELINE config 4: the chains of the reference's pdbs_test/ (53 chains, 1,641 - 3,052 atoms; coordinates,
     features, residue maps and the reference's logits are the parity fixture tests/golden/cfg4_all53.npz), repeated cyclically when
     more structures are asked for. Without the fixture: synthetic structures with the same size histogram.
     With a model the neighbour tables come from the GPU k-NN (pesto_knn_collate: the same exact table as the host contract, tested
     entry for entry on these chains; 64 structures in milliseconds instead of ~0.5 s of dense host work each).
+    forms: "compact" = what a loader that keeps encode_features' argmax hands over (uint8 feature indices, res_of_atom, uint16 ids -
+    reduced HERE, outside every timed region); "dense" = the reference loader's own outputs per structure, untouched: float32 one-hot q
+    (encode_features, src/data_encoding.py:78-84), BOOL mask M (encode_structure, :61-75), int64 ids (extract_topology, :87-102) - every
+    reduction (one-hot detection, mask -> segments, id narrowing) then happens inside the timed submit.
     Returns (structures, sizes, reference logits per structure or None)."""
     from pesto_amd.topology import synthetic_structure
     fx = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "cfg4_all53.npz")
@@ -230,7 +234,11 @@ def config4_structures(n_structures, model=None):
             for c, r, col, v in g["tie_patches"]:
                 for i in range(int(c), n_structures, n_chains):
                     items[i][1][r, col] = v
-    if model is not None and model.config["em"]["N0"] == 30:
+    if forms == "dense":
+        for it in items:
+            it[1] = np.ascontiguousarray(it[1].astype(np.int64)) if it[1] is not None else None
+            it[3] = np.ascontiguousarray(it[3] > 0.5)
+    elif model is not None and model.config["em"]["N0"] == 30:
         # the compact per-structure forms of forward_batch_submit, as a loader would hand them over (encode_features' argmax, the residue
         # column per atom, uint16 neighbour ids): the Python layer then touches no array element and the library packs bytes
         for it in items:
@@ -240,12 +248,14 @@ def config4_structures(n_structures, model=None):
     return [tuple(it) for it in items], sizes, refs
 
 
-def config4_leg(model, dist, backend, dev, n_structures, reps, max_atoms):
-    """Strong scaling: the SAME work list for every world size, sharded by pesto_amd.sharding (LPT partition, per-rank launches of
-    <= max_atoms atoms from host memory, ragged all_gather of the logits). Returns the leg's result dict on rank 0."""
+def config4_leg(model, dist, backend, dev, n_structures, reps, max_atoms, forms="compact", fixed_list=False):
+    """The config-4 work list sharded by pesto_amd.sharding (LPT partition, per-rank launches of <= max_atoms atoms from host memory,
+    ragged all_gather of the logits). fixed_list=False: n_structures grows with the world size (weak); True: the SAME list at every world
+    size (SURVEY 8e's acceptance: >= 7x on 8 GPUs for a list of >= 64 structures), with a world-1 pass of the list on rank 0 timed beside
+    it (`speedup_vs_world1`). Returns the leg's result dict on rank 0."""
     import torch
     from pesto_amd import sharding
-    structures, sizes, refs = config4_structures(n_structures, model)
+    structures, sizes, refs = config4_structures(n_structures, model, forms)
     n_out = model.config["dm"]["N2"]
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
@@ -272,6 +282,21 @@ def config4_leg(model, dist, backend, dev, n_structures, reps, max_atoms):
             el = float(t.item())
         times.append(el)
         per_rank.append(gather_rank_stats(dist, backend, dev, [tm["local_s"], tm["gather_s"], cpu_s, tm["structures"], tm["atoms"]]))
+    # world-1 pass of the same list on rank 0 alone (the other ranks wait at the barrier): the denominator of the fixed-list speed-up
+    t_world1 = None
+    if fixed_list:
+        barrier()
+        if rank == 0:
+            sharding.forward_local(model, structures, list(range(len(structures))), max_atoms=max_atoms)
+            torch.cuda.synchronize()
+            t1s = []
+            for _ in range(max(2, reps // 2)):
+                t0 = time.perf_counter()
+                sharding.forward_local(model, structures, list(range(len(structures))), max_atoms=max_atoms)
+                torch.cuda.synchronize()
+                t1s.append(time.perf_counter() - t0)
+            t_world1 = float(np.median(t1s))
+        barrier()
     if rank != 0:
         return None
     # world-1 run of the same list on this rank; every structure must come back with the same bits (PESTO_BATCH_INDEPENDENT)
@@ -289,8 +314,13 @@ def config4_leg(model, dist, backend, dev, n_structures, reps, max_atoms):
                         f"{max_atoms} atoms, inputs in HOST memory (packing + H2D inside the timed region, two launches in flight: "
                         f"pesto_forward_batch_submit / _wait), logits all-gathered to every rank "
                         f"({backend if world > 1 else 'no collective at world 1'})",
+            "inputs": ("dense: the reference loader's per-structure outputs as they are - float32 one-hot q, bool mask M, int64 ids; one-hot detection, "
+                       "mask -> segments and id narrowing INSIDE the timed region" if forms == "dense" else
+                       "compact, pre-reduced OUTSIDE the timed region: uint8 feature indices (argmax of q), res_of_atom (the member column of M), uint16 ids"),
             "structures": len(structures), "structures_per_rank": len(structures) // world, "value": len(structures) / t_med, "unit": "structures/s",
-            "scaling": "weak (the list grows with the world size: a fixed number of structures per rank)",
+            "scaling": ("strong (the same list at every world size)" if fixed_list else
+                        "weak (the list grows with the world size: a fixed number of structures per rank)"),
+            "seconds_world1_on_rank0": t_world1, "speedup_vs_world1": None if t_world1 is None else t_world1 / t_med,
             "seconds_per_pass_median": t_med, "passes": reps, "bitwise_equal_to_world1": bool(ok), "parity_max_abs_vs_reference": parity,
             # per rank (median over the passes): seconds in its own launches, seconds waiting in / doing the result gather, CPU seconds of
             # the rank's process (packing, submit / wait, gather), its share of the list - a straggler or a starved host shows here
@@ -317,8 +347,11 @@ def self_launch(args):
     """`python bench.py --gpus N` without a launcher: become N ranks under torch.distributed.run (one per GPU)."""
     import torch
     if not args.same_gpu and torch.cuda.device_count() < args.gpus:
-        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible "
-                         "(--same-gpu with --backend gloo runs the multi-rank path on one GPU, for testing)")
+        msg = (f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible "
+               "(--same-gpu with --backend gloo runs the multi-rank path on one GPU, for testing)")
+        print(json.dumps({"metric": "structures/sec (N=3000 atoms, k=64, 32 layers)", "value": None, "unit": "structures/s", "n_gpus": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup, "error": msg, "error_stage": "self launch", "visible_gpus": int(torch.cuda.device_count())}), flush=True)
+        raise SystemExit(msg)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -346,6 +379,7 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="developer ablation builds only: do not check the timed output")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 and config-4 legs (profiling runs)")
     ap.add_argument("--config4-structures", type=int, default=64, help="structures PER RANK of the config-4 leg (the list has this many x world size)")
+    ap.add_argument("--strong-structures", type=int, default=512, help="size of the FIXED list of the config4_strong leg (N > 1 only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="testing only: every rank uses GPU 0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
@@ -356,6 +390,31 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    stage = ["start"]
+    try:
+        run(args, stage)
+    except SystemExit:
+        raise
+    except BaseException as e:      # noqa: BLE001 - the driver reads ONE JSON line from stdout: a failure becomes that line, the traceback goes to stderr
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "structures/sec (N=3000 atoms, k=64, 32 layers)", "value": None, "unit": "structures/s", "n_gpus": args.gpus,
+                              "steps": args.steps, "warmup": args.warmup, "error": f"{type(e).__name__}: {e}"[:600], "error_stage": stage[0],
+                              "world_size_env": os.environ.get("WORLD_SIZE"), "local_rank_env": os.environ.get("LOCAL_RANK"),
+                              "visible_gpus": _visible_gpus()}), flush=True)
+        sys.exit(1)
+
+
+def _visible_gpus():
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def run(args, stage):
 
     import torch
     from pesto_amd import Model
@@ -364,14 +423,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    stage[0] = "device check"
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+        raise RuntimeError(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the forward pass)")
+        raise RuntimeError("bench.py needs an MI355X (no CPU fallback exists for the forward pass)")
+    if not args.same_gpu and torch.cuda.device_count() <= local_rank:
+        raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     gpu = 0 if args.same_gpu else local_rank
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
     dist = None
+    stage[0] = "process group init (torch.distributed, backend %s)" % args.backend
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -391,15 +454,23 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
+    stage[0] = "weight broadcast / handle creation"
     config = CONFIGS[args.config]
     n0 = config["em"]["N0"]
-    sd, wdesc = load_weights(config)
+    # the weights: rank 0 reads them, every rank builds its handle from the BROADCAST blob (one collective over device tensors under RCCL;
+    # sharding.broadcast_weights compares a checksum across the ranks) - SURVEY 8e "init: ncclBroadcast(weights)"
+    from pesto_amd import sharding as _sh
+    sd, wdesc = load_weights(config) if (rank == 0 or world == 1) else (None, None)
     model = Model(config, validate=False, precision=args.precision).to(dev)
-    model.load_state_dict(sd)
+    wb = _sh.broadcast_weights(model, sd if rank == 0 else None, src=0, device=dev)
+    if wdesc is None:
+        wdesc = "weights received from rank 0"
+    ranks_info = _sh.describe_ranks(dev)
     if args.edge_mode:
         model.debug_edge_mode(args.edge_mode)
 
     # ---- inputs: one batch per rank, resident in HBM before the timed region
+    stage[0] = "timed steps"
     X, ids, q, roa, R = make_batch(args.atoms, args.batch, 1000 * rank + 1, n0, args.order)
     Xd = torch.from_numpy(X).to(dev)
     idsd = torch.from_numpy(ids).to(dev)            # int64, as the reference passes it
@@ -614,9 +685,19 @@ def main():
         lat_ms = (time.perf_counter() - t1) / 10 * 1e3
 
     # ---- BASELINE config 4 as a strong-scaling leg (every world size runs the same list)
-    cfg4 = None
+    stage[0] = "config-4 legs (sharding.forward_sharded)"
+    cfg4 = cfg4_dense = cfg4_strong = None
     if (not args.no_extras or args.mode == "strong") and args.config == "i_v4_1":
         cfg4 = config4_leg(model, dist, args.backend, dev, args.config4_structures * world, max(3, min(args.steps, 5)), 24576)
+        # the same list in the reference loader's OWN per-structure forms (dense one-hot q, bool M, int64 ids): every reduction inside the
+        # timed region (ADVICE r4 / VERDICT r4 item 6: the compact leg above pre-reduces outside it)
+        cfg4_dense = config4_leg(model, dist, args.backend, dev, args.config4_structures * world, 3, 24576, forms="dense")
+        if world > 1:
+            # SURVEY 8e's acceptance is about a FIXED list (>= 7x on 8 GPUs, >= 64 structures): the same 512 structures at every world
+            # size, with the world-1 time of that list taken on rank 0 inside this run
+            cfg4_strong = config4_leg(model, dist, args.backend, dev, args.strong_structures, 3, 24576, fixed_list=True)
+        if rank == 0 and cfg4 is not None:
+            cfg4["dense_forms"] = cfg4_dense
 
     if rank == 0:
         n_struct = args.steps * args.batch * world
@@ -662,6 +743,10 @@ def main():
             "roofline": roofline,
             "whole_forward": whole,
             "config4_sharded": cfg4,
+            "config4_strong": cfg4_strong,
+            # what the collective library saw: ranks counted by an all_reduce of ones (device tensors under nccl = RCCL), the device of every
+            # rank, and the weight broadcast every handle was built from
+            "rccl_ranks_seen": ranks_info["ranks_seen"], "ranks": ranks_info, "weights_broadcast": wb,
         }
         if args.cpu_budget > 0 and world == 1:      # the CPU baseline is a 1-GPU-run side measurement (rank 0, N = 1 only)
             key = {"i_v4_1": "2:", "i_v3_0": "3:"}.get(args.config, "2:")

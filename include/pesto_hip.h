@@ -80,7 +80,9 @@ typedef struct pesto_config {
 typedef struct pesto_model pesto_model;
 
 enum { PESTO_PTR_HOST = 0, PESTO_PTR_DEVICE = 1 };
-enum { PESTO_IDS_INT32 = 32, PESTO_IDS_INT64 = 64, PESTO_IDS_UINT16 = 16 /* pesto_forward_batch_submit only */ };
+enum { PESTO_IDS_INT32 = 32, PESTO_IDS_INT64 = 64, PESTO_IDS_UINT16 = 16 /* pesto_forward_batch_submit only */,
+       PESTO_IDS_NARROW = 0x100 /* pesto_forward_batch_submit only, OR-ed to INT32 / INT64: stage the table as uint16 (narrowed and range-checked
+                                   while it is packed) when every structure has <= 65,536 atoms */ };
 
 const char* pesto_last_error(void);
 
@@ -100,6 +102,19 @@ int pesto_get_status(const pesto_model* m, int32_t* precision, int64_t* n_forwar
 /* enabled != 0: device-pointer forwards under PESTO_PRECISION_AUTO return without synchronising; their range / input check is made by
  * the next call on the handle (see pesto_precision). Default 0: checked before the call returns. No reference counterpart. */
 int pesto_set_async_auto(pesto_model* m, int32_t enabled);
+/* Conditioning trigger of PESTO_PRECISION_AUTO (round 5; no reference counterpart - torch computes in fp32 throughout,
+ * src/model_operations.py:109-152). The f16 hi/lo split drops a term of 2^-22 RELATIVE size per product, so the absolute error of the
+ * logits grows with the magnitude of the states. A structure whose new state exceeds `limit` (max |q|, |p| of any atom) in any layer is
+ * flagged like a range overflow and repeated on the exact fp32 kernels (counted by pesto_get_status). limit <= 0 switches the trigger
+ * off; F16_SPLIT and FP32 ignore it.
+ * Calibration (profiles/r05_state_limit.txt): the states of REAL structures reach 48 - 96 on a few of the 53 pdbs_test chains (three
+ * chains above 48, one above 64 with the i_v4_1 architecture, none above 96) while their logits stay within 3e-5 of the reference, and the
+ * two pinned ill-conditioned random clouds (tests/golden/fuzz_pins.npz, |p| ~ 50) sit BELOW that - state magnitude does not separate
+ * them, so the default is a safety net between the sizes trained models produce and the f16 range (65,504), not a tuned detector:
+ * 128 fires on none of the reference's test structures. (The pinned inputs themselves are at 8.3e-5 / 8.2e-5 from the reference's fp64
+ * logits with the trigger off; a caller that wants the exact kernels on such inputs sets a lower limit or PESTO_PRECISION_FP32.) */
+#define PESTO_AUTO_STATE_LIMIT_DEFAULT 128.0f
+int pesto_set_auto_state_limit(pesto_model* m, float limit);
 
 /* replaces: Model.forward(X, ids_topk, q0, M)  (model/model.py:32-52).
  * ptr_kind: PESTO_PTR_HOST (library stages H2D/D2H itself) or PESTO_PTR_DEVICE (all five buffers on

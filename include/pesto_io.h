@@ -82,6 +82,11 @@ int pesto_io_format_pdb(pesto_structure* s, const float* bfactor, int64_t n_valu
  * with zero or several members or an empty column (the reference's dense softmax degenerates there). Host arrays; the mask on the
  * GPU is reduced by pesto_mask_to_segments (pesto_hip.h). */
 int pesto_io_mask_to_segments(const float* M, int64_t N, int64_t R, int32_t* res_of_atom);
+/* the same for a mask of 1-byte elements - what encode_structure itself returns (numpy bool, src/data_encoding.py:61-75; callers only
+ * turn it into floats for torch, apply_model.ipynb:155) - or 4-byte floats (elem_bytes 1 | 4). Every row is checked in full (byte / word
+ * sums, AVX2 where the host has it); the member's column is looked for at the previous row's column and the one after it first (the
+ * reference's columns follow the contiguous residue numbering of clean_structure, src/structure.py:47), anywhere else otherwise. */
+int pesto_io_mask_to_segments_any(const void* M, int32_t elem_bytes, int64_t N, int64_t R, int32_t* res_of_atom);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("PESTO_LIB") or os.path.join(_HERE, "csrc", "libpesto_
 
 PTR_HOST, PTR_DEVICE = 0, 1
 IDS_INT32, IDS_INT64, IDS_UINT16 = 32, 64, 16
+IDS_NARROW = 0x100      # OR-ed to IDS_INT32 / IDS_INT64 (pesto_forward_batch_submit): staged as uint16, narrowed and range-checked by the packer
 BATCH_COLLATED, BATCH_INDEPENDENT = 0, 1
 # enum pesto_precision
 PRECISIONS = {"auto": 0, "f16_split": 1, "fp32": 2}
@@ -61,7 +62,7 @@ ABI_SYMBOLS = [
     "pesto_forward_frames", "pesto_postprocess", "pesto_forward_batch", "pesto_get_kernel_timing",
     "pesto_set_precision", "pesto_get_status", "pesto_debug_select", "pesto_forward_structures",
     "pesto_mask_to_segments", "pesto_debug_edge_mode", "pesto_forward_batch_submit", "pesto_forward_batch_wait",
-    "pesto_set_async_auto", "pesto_debug_host_only", "pesto_knn_tie_rows",
+    "pesto_set_async_auto", "pesto_debug_host_only", "pesto_knn_tie_rows", "pesto_set_auto_state_limit",
 ]
 
 _lib = None
@@ -104,6 +105,7 @@ def load():
     lib.pesto_forward_batch_wait.argtypes = [c_p, i32]
     lib.pesto_set_precision.argtypes = [c_p, i32]
     lib.pesto_set_async_auto.argtypes = [c_p, i32]
+    lib.pesto_set_auto_state_limit.argtypes = [c_p, ctypes.c_float]
     lib.pesto_debug_host_only.argtypes = [c_p, i32]
     lib.pesto_get_status.argtypes = [c_p, P(i32), P(i64), P(i64)]
     lib.pesto_debug_select.argtypes = [c_p, i32, i32]

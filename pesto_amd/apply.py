@@ -63,9 +63,21 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
     model.set_async_auto(True)
     try:
         _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_error, results, dev, n0, report_ties)
-    finally:
-        model.synchronize()
-        model.set_async_auto(was_async)
+    except BaseException:
+        # the loop failed: still drain the handle and restore its mode, but the deferred check of the last launch (model.synchronize() may
+        # raise its bad-input / range error) must not replace the exception that is already in flight
+        try:
+            model.synchronize()
+        except Exception:
+            pass
+        finally:
+            model.set_async_auto(was_async)
+        raise
+    else:
+        try:
+            model.synchronize()
+        finally:
+            model.set_async_auto(was_async)
     if results_path is not None:
         save_results(results, results_path)
     return results

@@ -2,6 +2,7 @@
 // workspace, the forward launch sequence on one HIP stream, per-stage entry points for the parity tests.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,8 @@ struct pesto_model {
     int64_t n_forward = 0, n_rerun = 0;    // launch sequences run / STRUCTURES repeated on the exact fp32 kernels after a range overflow
     DevBuf sflags;                         // range guard: one word per structure (frame) of the launch (SatCtx)
     std::vector<int> h_sflags;             // host copy (counting the structures a repeat covers)
+    std::vector<int> knn_off_host;         // the structure offsets knn_off holds on the device (pesto_knn_collate / pesto_knn_tie_rows)
+    float state_limit = PESTO_AUTO_STATE_LIMIT_DEFAULT;   // pesto_set_auto_state_limit: conditioning trigger of AUTO (SatCtx::state_limit)
     bool async_auto = false;               // pesto_set_async_auto: device-pointer calls under AUTO defer their check to the next call
     // every launch sequence uses the ONE workspace below: sequences on different streams are ordered through this event
     hipEvent_t ws_ev = nullptr;
@@ -224,7 +227,9 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
     const size_t seg_off = (n_dmax + 3) / 4 * 4;      // (in ints)
     const size_t clear_bytes = ((seg_off + 2 * (size_t)RT) * 4 + 63) / 64 * 64;      // (a multiple of 64 bytes: one fill kernel, no tail launch)
     if (m->dmax.ensure(clear_bytes) || m->sflags.ensure(n_dmax * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
-    const SatCtx sc{err_ptr(m), m->sflags.as<int>(), a.seg_of_atom, (!a.seg_of_atom && a.F > 1) ? (int)a.N : 0};
+    // conditioning trigger: only where a flagged structure is repeated (AUTO on the split kernels); f16_split never repeats, so it never flags
+    const float state_limit = (!exact && m->precision == PESTO_PRECISION_AUTO && m->state_limit > 0.0f) ? m->state_limit : __builtin_huge_valf();
+    const SatCtx sc{err_ptr(m), m->sflags.as<int>(), a.seg_of_atom, (!a.seg_of_atom && a.F > 1) ? (int)a.N : 0, state_limit};
     int* seg_lo = m->dmax.as<int>() + seg_off;
     int* seg_hi = seg_lo + RT;
     const bool bounds_in_embed = a.F == 1;             // found by the unpack launch (trajectory batches expand res_of_atom per frame behind it: separate launches)
@@ -513,6 +518,14 @@ int pesto_set_async_auto(pesto_model* m, int32_t enabled) {
     if (check_model(m)) return PESTO_ERR_INVALID;
     if (int rc = resolve_pending(m)) return rc;
     m->async_auto = enabled != 0;
+    return 0;
+}
+
+int pesto_set_auto_state_limit(pesto_model* m, float limit) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (limit != limit) return fail(PESTO_ERR_INVALID, "state limit must be a number (<= 0 switches the trigger off)");
+    if (int rc = resolve_pending(m)) return rc;
+    m->state_limit = limit;
     return 0;
 }
 
@@ -812,7 +825,15 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
     if (batch_mode != PESTO_BATCH_COLLATED && batch_mode != PESTO_BATCH_INDEPENDENT)
         return fail(PESTO_ERR_INVALID, "batch_mode must be PESTO_BATCH_COLLATED or PESTO_BATCH_INDEPENDENT");
     if (n_struct < 1 || !N || !R || !k || !X || !ids_topk0 || (!q0 && !q_index) || !res_of_atom || !z_out || !ticket) return fail(PESTO_ERR_INVALID, "bad arguments");
-    if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64 && ids_kind != PESTO_IDS_UINT16) return fail(PESTO_ERR_INVALID, "ids_kind must be 16, 32 or 64");
+    // PESTO_IDS_NARROW: int32 / int64 tables (what extract_topology hands out, src/data_encoding.py:98-102) travel as uint16 - narrowed and
+    // range-checked by the packer's own pass over them, not by three numpy passes in the caller - when every structure has <= 65,536 atoms
+    const bool want_narrow = (ids_kind & PESTO_IDS_NARROW) != 0;
+    const int src_kind = ids_kind & ~PESTO_IDS_NARROW;
+    if (src_kind != PESTO_IDS_INT32 && src_kind != PESTO_IDS_INT64 && src_kind != PESTO_IDS_UINT16) return fail(PESTO_ERR_INVALID, "ids_kind must be 16, 32 or 64");
+    if (want_narrow && src_kind == PESTO_IDS_UINT16) return fail(PESTO_ERR_INVALID, "PESTO_IDS_NARROW goes with int32 / int64 tables");
+    bool narrow = want_narrow;
+    for (int s_ = 0; s_ < n_struct && narrow; ++s_) narrow = N && N[s_] <= 65536;
+    ids_kind = narrow ? PESTO_IDS_UINT16 : src_kind;      // (the kind the staged table has)
     if (q_index && (n_index < 1 || n_index > 3 || !index_offsets)) return fail(PESTO_ERR_INVALID, "q_index needs 1..3 index columns and their block offsets");
     const bool detect = !q_index && n_index > 0;      // dense q0 + the block offsets: find the indices while packing (below)
     if (detect && (n_index > 3 || !index_offsets)) return fail(PESTO_ERR_INVALID, "index_offsets: 1..3 block offsets");
@@ -844,23 +865,8 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
         int bounds[4] = {0, 0, 0, 0};
         for (int c = 0; c < n_index; ++c) bounds[c] = index_offsets[c];
         bounds[n_index] = n0;
-        for (int s_ = 0; s_ < n_struct && onehot; ++s_) {
-            const float* qs = q0[s_];
-            uint8_t* dst = m->qidx_host.data() + (size_t)meta[s_].off * n_index;
-            for (int64_t i = 0; i < N[s_] && onehot; ++i) {
-                const float* row = qs + i * n0;
-                for (int c = 0; c < n_index; ++c) {
-                    int at = -1, ones = 0, other = 0;
-                    for (int f = bounds[c]; f < bounds[c + 1]; ++f) {
-                        if (row[f] == 1.0f) { at = f; ++ones; }
-                        else if (row[f] != 0.0f) ++other;
-                    }
-                    if (ones != 1 || other != 0 || at - bounds[c] > 255) { onehot = false; break; }
-                    dst[i * n_index + c] = (uint8_t)(at - bounds[c]);
-                }
-                for (int f = 0; f < bounds[0] && onehot; ++f) if (row[f] != 0.0f) onehot = false;      // (features in front of the first block)
-            }
-        }
+        for (int s_ = 0; s_ < n_struct && onehot; ++s_)       // (vectorised scans, pesto_schema.cpp)
+            onehot = onehot_rows_to_indices(q0[s_], N[s_], n0, bounds, n_index, m->qidx_host.data() + (size_t)meta[s_].off * n_index);
         if (onehot) {
             qi_ptr.resize((size_t)n_struct);
             for (int s_ = 0; s_ < n_struct; ++s_) qi_ptr[s_] = m->qidx_host.data() + (size_t)meta[s_].off * n_index;
@@ -909,7 +915,12 @@ int pesto_forward_batch_submit(pesto_model* m, int32_t n_struct, const int64_t* 
     for (int s_ = 0; s_ < n_struct; ++s_) {
         const CollMeta& mb = meta[s_];
         memcpy(h + b.off_X + (size_t)mb.off * 12, X[s_], (size_t)mb.n * 12);
-        memcpy(h + b.off_ids + (size_t)mb.idoff * id_sz, ids_topk0[s_], (size_t)mb.n * mb.k * id_sz);
+        if (narrow) {
+            if (!narrow_ids_to_u16(ids_topk0[s_], src_kind, (size_t)mb.n * mb.k, reinterpret_cast<uint16_t*>(h + b.off_ids + (size_t)mb.idoff * 2)))
+                return fail(PESTO_ERR_INVALID, "structure %d: ids_topk has entries outside [0, N)", s_);
+        } else {
+            memcpy(h + b.off_ids + (size_t)mb.idoff * id_sz, ids_topk0[s_], (size_t)mb.n * mb.k * id_sz);
+        }
         if (q_index) memcpy(h + b.off_q + (size_t)mb.off * n_index, q_index[s_], (size_t)mb.n * n_index);
         else memcpy(h + b.off_q + (size_t)mb.off * n0 * 4, q0[s_], (size_t)mb.n * n0 * 4);
         memcpy(h + b.off_roa + (size_t)mb.off * 4, res_of_atom[s_], (size_t)mb.n * 4);
@@ -968,6 +979,7 @@ int pesto_forward_batch_wait(pesto_model* m, int32_t ticket) {
 int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
                       void* ids_out, int32_t ids_kind, int32_t ptr_kind, void* stream) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;      // a deferred AUTO repeat reads workspace words (guard words, SatCtx, segment maps) this call overwrites
     if (n_total < 1 || n_total > 0x7ffffff0 / 96 || n_struct < 1 || !struct_offsets || !X || !ids_out || k < 1 || k > KMAX)
         return fail(PESTO_ERR_INVALID, "bad arguments");
     if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
@@ -986,6 +998,7 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
         host_tab[n_struct + 1 + s] = (!brute && struct_offsets[s + 1] - struct_offsets[s] >= knn_cell_min()) ? n_slots++ : -1;
     const int use_grid = n_slots > 0;
     if (m->knn_off.ensure(host_tab.size() * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    m->knn_off_host.assign(struct_offsets, struct_offsets + n_struct + 1);      // (what the upload below leaves on the device)
     if (use_grid) {
         const size_t cells = (size_t)n_slots * knn_cells_per_struct();
         if (m->knn_grids.ensure((size_t)n_struct * knn_grid_struct_bytes()) || m->knn_cnt.ensure(cells * 4) || m->knn_cur.ensure(cells * 4) ||
@@ -1024,6 +1037,7 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
 int pesto_knn_tie_rows(pesto_model* m, int64_t n_total, int32_t n_struct, const int32_t* struct_offsets, const float* X, int32_t k,
                        const void* ids, int32_t ids_kind, uint8_t* flags_out, int32_t ptr_kind, void* stream) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;      // a deferred AUTO repeat reads workspace words (guard words, SatCtx, segment maps) this call overwrites
     if (n_total < 1 || n_total > 0x7ffffff0 / 96 || n_struct < 1 || !struct_offsets || !X || !ids || !flags_out || k < 1 || k > KMAX)
         return fail(PESTO_ERR_INVALID, "bad arguments");
     if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
@@ -1033,12 +1047,20 @@ int pesto_knn_tie_rows(pesto_model* m, int64_t n_total, int32_t n_struct, const 
         if (struct_offsets[s + 1] <= struct_offsets[s]) return fail(PESTO_ERR_INVALID, "empty or unordered structure %d", s);
     HIP_TRY(hipSetDevice(m->device));
     const size_t id_sz = ids_kind == PESTO_IDS_INT64 ? 8 : 4;
+    if (m->knn_off.cap < ((size_t)2 * n_struct + 1) * 4) m->knn_off_host.clear();      // (a reallocation drops the device copy)
     if (m->knn_off.ensure(((size_t)2 * n_struct + 1) * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
     hipStream_t st = ptr_kind == PESTO_PTR_DEVICE ? (hipStream_t)stream : (stream ? (hipStream_t)stream : m->stream);
     Sequence seq(m, st);
     if (seq.rc) return seq.rc;
-    HIP_TRY(hipMemcpyAsync(m->knn_off.p, struct_offsets, ((size_t)n_struct + 1) * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));           // struct_offsets is the caller's: finish the copy before returning
+    // the usual caller asks for the tie rows of the table pesto_knn_collate has just built: the same offsets are on the device already
+    // (no copy, and no stream synchronisation inside a loop that is meant to stay asynchronous - ADVICE r4)
+    const bool same_offsets = m->knn_off_host.size() == (size_t)n_struct + 1 &&
+                              std::equal(m->knn_off_host.begin(), m->knn_off_host.end(), struct_offsets);
+    if (!same_offsets) {
+        HIP_TRY(hipMemcpyAsync(m->knn_off.p, struct_offsets, ((size_t)n_struct + 1) * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));           // struct_offsets is the caller's: finish the copy before returning
+        m->knn_off_host.assign(struct_offsets, struct_offsets + n_struct + 1);
+    }
     if (ptr_kind == PESTO_PTR_DEVICE) {
         launch_knn_ties(st, (int)n_total, n_struct, m->knn_off.as<int>(), X, k, ids, ids_kind, flags_out);
         HIP_TRY(hipGetLastError());
@@ -1062,6 +1084,7 @@ int pesto_knn_tie_rows(pesto_model* m, int64_t n_total, int32_t n_struct, const 
 
 int pesto_mask_to_segments(pesto_model* m, int64_t N, int64_t R, const float* M, int32_t* res_of_atom_out, int32_t ptr_kind, void* stream) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;      // a deferred AUTO repeat reads workspace words (guard words, SatCtx, segment maps) this call overwrites
     if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || R > N || !M || !res_of_atom_out) return fail(PESTO_ERR_INVALID, "bad arguments");
     if (ptr_kind != PESTO_PTR_HOST && ptr_kind != PESTO_PTR_DEVICE) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
     HIP_TRY(hipSetDevice(m->device));
@@ -1133,6 +1156,7 @@ int pesto_postprocess(pesto_model* m, int64_t N, int64_t R, const float* z, cons
 // ------------------------------------------------------------------ per-stage entry points (host pointers)
 int pesto_stage_embed(pesto_model* m, int64_t N, const float* q0, float* q_out) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;      // a deferred AUTO repeat reads workspace words (guard words, SatCtx, segment maps) this call overwrites
     if (N < 1 || !q0 || !q_out) return fail(PESTO_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(m->device));
     if (int rc = ensure_workspace(m, N, 1)) return rc;
@@ -1151,6 +1175,7 @@ int pesto_stage_embed(pesto_model* m, int64_t N, const float* q0, float* q_out) 
 int pesto_stage_unpack(pesto_model* m, int64_t N, int32_t k, const float* X, const void* ids_topk, int32_t ids_kind,
                        float* D_out, float* R_out) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;      // a deferred AUTO repeat reads workspace words (guard words, SatCtx, segment maps) this call overwrites
     if (N < 1 || k < 1 || k > KMAX || !X || !ids_topk) return fail(PESTO_ERR_INVALID, "bad arguments");
     if (ids_kind != PESTO_IDS_INT32 && ids_kind != PESTO_IDS_INT64) return fail(PESTO_ERR_INVALID, "ids_kind must be 32 or 64");
     HIP_TRY(hipSetDevice(m->device));
@@ -1184,6 +1209,7 @@ int pesto_stage_unpack(pesto_model* m, int64_t N, int32_t k, const float* X, con
 
 int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;      // a deferred AUTO repeat reads workspace words (guard words, SatCtx, segment maps) this call overwrites
     if (m->stage_N < 1) return fail(PESTO_ERR_STATE, "pesto_stage_unpack must run first");
     if (layer < 0 || layer >= m->cfg.n_layers || !q_io || !p_io) return fail(PESTO_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(m->device));
@@ -1225,6 +1251,7 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
 int pesto_stage_pool(pesto_model* m, int64_t N, int64_t R, const float* q, const float* p, const int32_t* res_of_atom,
                      float* qr_out, float* pr_out, float* z_out) {
     if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;      // a deferred AUTO repeat reads workspace words (guard words, SatCtx, segment maps) this call overwrites
     if (N < 1 || R < 1 || !q || !p || !res_of_atom || !z_out) return fail(PESTO_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(m->device));
     if (int rc = ensure_workspace(m, N, R)) return rc;

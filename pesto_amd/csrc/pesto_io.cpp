@@ -19,6 +19,9 @@
 #include <string>
 #include <unordered_set>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "../../include/pesto_io.h"
 
@@ -35,6 +38,55 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+
+// ---- row sums for the dense-mask reduction (pesto_io_mask_to_segments_any): plain C++ and an AVX2 twin chosen at run time (the library is
+// built in one container and runs on another host: no -march flags)
+bool have_avx2() {
+    static const bool v = __builtin_cpu_supports("avx2");
+    return v;
+}
+uint64_t row_sum_u8(const uint8_t* row, int64_t n) {
+    uint64_t s = 0;
+    for (int64_t r = 0; r < n; ++r) s += row[r];
+    return s;
+}
+uint64_t row_sum_u32(const uint32_t* row, int64_t n) {
+    uint64_t s = 0;
+    for (int64_t r = 0; r < n; ++r) s += row[r];
+    return s;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) uint64_t row_sum_u8_avx2(const uint8_t* row, int64_t n) {
+    __m256i acc = _mm256_setzero_si256();
+    const __m256i zero = _mm256_setzero_si256();
+    int64_t r = 0;
+    for (; r + 32 <= n; r += 32) acc = _mm256_add_epi64(acc, _mm256_sad_epu8(_mm256_loadu_si256((const __m256i*)(row + r)), zero));
+    uint64_t lanes[4];
+    _mm256_storeu_si256((__m256i*)lanes, acc);
+    uint64_t s = lanes[0] + lanes[1] + lanes[2] + lanes[3];
+    for (; r < n; ++r) s += row[r];
+    return s;
+}
+__attribute__((target("avx2"))) uint64_t row_sum_u32_avx2(const uint32_t* row, int64_t n) {
+    // 32-bit lanes cannot overflow into a false 0x3f800000 unnoticed: a second accumulator ORs the words, and a valid row's OR equals its sum
+    __m256i acc = _mm256_setzero_si256(), any = _mm256_setzero_si256();
+    int64_t r = 0;
+    for (; r + 8 <= n; r += 8) {
+        const __m256i v = _mm256_loadu_si256((const __m256i*)(row + r));
+        acc = _mm256_add_epi32(acc, v);
+        any = _mm256_or_si256(any, v);
+    }
+    uint32_t a[8], o[8];
+    _mm256_storeu_si256((__m256i*)a, acc); _mm256_storeu_si256((__m256i*)o, any);
+    uint64_t s = 0; uint32_t orv = 0;
+    for (int k = 0; k < 8; ++k) { s += a[k]; orv |= o[k]; }
+    for (; r < n; ++r) { s += row[r]; orv |= row[r]; }
+    return (s == 0x3f800000u && orv == 0x3f800000u) ? s : ~0ull;
+}
+#else
+uint64_t row_sum_u8_avx2(const uint8_t* row, int64_t n) { return row_sum_u8(row, n); }
+uint64_t row_sum_u32_avx2(const uint32_t* row, int64_t n) { return row_sum_u32(row, n); }
+#endif
 
 // the reference's dict of per-atom numpy arrays
 struct Atoms {
@@ -644,21 +696,49 @@ int pesto_io_write_pdb(const pesto_structure* s, const float* bfactor, int64_t n
 
 /* dense residue mask -> residue column per atom, one pass over the rows (the numpy form makes four) */
 int pesto_io_mask_to_segments(const float* M, int64_t N, int64_t R, int32_t* res_of_atom) {
+    return pesto_io_mask_to_segments_any(M, 4, N, R, res_of_atom);
+}
+
+int pesto_io_mask_to_segments_any(const void* M, int32_t elem_bytes, int64_t N, int64_t R, int32_t* res_of_atom) {
     if (!M || !res_of_atom || N < 1 || R < 1 || R > 0x7fffffff) return fail(PESTO_IO_ERR_INVALID, "bad arguments");
+    if (elem_bytes != 1 && elem_bytes != 4) return fail(PESTO_IO_ERR_INVALID, "mask elements must be 1 byte (bool / uint8) or 4 bytes (float32)");
     std::vector<unsigned char> seen((size_t)R, 0);
+    const bool wide = have_avx2();
+    int64_t hint = 0;      // column of the previous row: the reference's columns are unique(resid) of a contiguously numbered structure, so a
+                           // row's member is the previous row's column or the next one (src/structure.py:47, src/data_encoding.py:73) - tried first
     for (int64_t i = 0; i < N; ++i) {
-        const float* row = M + i * R;
-        // branch-free so that the compiler vectorises the row scan: members = sum of (M > 0.5), at = sum of r (M > 0.5) - the member's
-        // column when there is exactly one
-        int members = 0, at = 0;
-        for (int r = 0; r < (int)R; ++r) {
-            const int hit = row[r] > 0.5f ? 1 : 0;
-            members += hit;
-            at += hit * r;
+        int64_t at = -1;
+        if (elem_bytes == 1) {
+            const uint8_t* row = (const uint8_t*)M + i * R;
+            // EXACT test of the whole row in one pass of byte sums (no per-element branch): the bytes of a valid row add up to 1
+            const uint64_t total = wide ? row_sum_u8_avx2(row, R) : row_sum_u8(row, R);
+            if (total != 1) {
+                int members = 0;
+                for (int64_t r = 0; r < R; ++r) members += row[r] != 0;
+                if (members != 1) return fail(PESTO_IO_ERR_INVALID, "M: atom %lld belongs to %d residues (every atom must belong to exactly one)", (long long)i, members);
+            }
+            if (row[hint] != 0) at = hint;
+            else if (hint + 1 < R && row[hint + 1] != 0) at = hint + 1;
+            else for (int64_t r = 0; r < R; ++r) if (row[r] != 0) { at = r; break; }
+        } else {
+            const float* row = (const float*)M + i * R;
+            // a valid row is one 1.0f among +0.0f: as integers its words add up to exactly 0x3f800000 and no word but the member's is
+            // set. Anything else (other values above 0.5, -0.0f, several members) takes the element-wise statement of the contract.
+            const uint64_t total = wide ? row_sum_u32_avx2((const uint32_t*)row, R) : row_sum_u32((const uint32_t*)row, R);
+            if (total == 0x3f800000u) {
+                if (row[hint] == 1.0f) at = hint;
+                else if (hint + 1 < R && row[hint + 1] == 1.0f) at = hint + 1;
+                else for (int64_t r = 0; r < R; ++r) if (row[r] == 1.0f) { at = r; break; }
+            }
+            if (at < 0) {      // (also reached by a row whose words happen to add up to 0x3f800000 without holding a 1.0f)
+                int members = 0;
+                for (int64_t r = 0; r < R; ++r) if (row[r] > 0.5f) { ++members; at = r; }
+                if (members != 1) return fail(PESTO_IO_ERR_INVALID, "M: atom %lld belongs to %d residues (every atom must belong to exactly one)", (long long)i, members);
+            }
         }
-        if (members != 1) return fail(PESTO_IO_ERR_INVALID, "M: atom %lld belongs to %d residues (every atom must belong to exactly one)", (long long)i, members);
         res_of_atom[i] = (int32_t)at;
         seen[(size_t)at] = 1;
+        hint = at;
     }
     for (int64_t r = 0; r < R; ++r)
         if (!seen[(size_t)r]) return fail(PESTO_IO_ERR_INVALID, "M: residue column %lld is empty", (long long)r);

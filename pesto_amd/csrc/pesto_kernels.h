@@ -17,7 +17,11 @@ struct ClearArgs { int* p0 = nullptr; int n0 = 0; int* p1 = nullptr; int n1 = 0;
 // ragged batch with separate-call semantics, (i - 1) / frame_n for trajectory frames, 0 for a plain collated call (both null / 0).
 // The context lives in device memory SATCTX_OFFSET_INTS ints behind the flags word the layer kernels get (written by the embed launch,
 // the first of every forward): the kernels' hot paths carry no extra arguments, only the rare flagging path reads it.
-struct SatCtx { int* flags = nullptr; int* sflags = nullptr; const int* seg_of_atom = nullptr; int frame_n = 0; };
+// state_limit: conditioning trigger of PESTO_PRECISION_AUTO (round 5, include/pesto_hip.h::pesto_set_auto_state_limit). The split's dropped
+// term is 2^-22 RELATIVE, so its absolute error grows with the states. A finishing wave that sees max |new state| of a centre above the
+// limit sets the SAME guard bit as an overflow: the structure is repeated on the exact kernels. +inf (precision f16_split / fp32, or the
+// trigger switched off) = never.
+struct SatCtx { int* flags = nullptr; int* sflags = nullptr; const int* seg_of_atom = nullptr; int frame_n = 0; float state_limit = __builtin_huge_valf(); };
 constexpr int SATCTX_OFFSET_INTS = 3;      // flags buffer: [0] unused, [1] the flags word, [2] collate's copy, [3] pad, [4..] SatCtx (16-byte aligned)
 void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero = nullptr,
                   ClearArgs clr = ClearArgs(), SatCtx sc = SatCtx());      // sc.flags non-null: the context is stored behind that word

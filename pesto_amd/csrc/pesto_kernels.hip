@@ -825,20 +825,32 @@ __global__ __launch_bounds__(256) void k_knn_ties(int n_total, int n_struct, con
     const long long id = lane < k ? (long long)ids[(size_t)i * KMAX + lane] : 0;
     const bool have = id > 0;
     const unsigned mykey = have ? dkey((int)id - 1) : 0xffffffffu;
-    unsigned out = 0;
+    // the four cut keys first, then ONE scan over the structure's atoms counting all four (round 4 scanned once per cut). The atom itself is
+    // left out on both sides - as a column (structures of <= 64 atoms list it, masked, at the end) and in the scan: its own distance-0 key
+    // used to count as a tie with every coincident atom and over-reported rows of structures with duplicated coordinates.
+    unsigned kc[4];
+    int inside[4], all[4] = {0, 0, 0, 0};
+    bool live[4];
+    const bool mine = have && (int)id - 1 != i;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int cut = 8 << c;
-        if (cut > k) continue;
-        const long long id_last = ids[(size_t)i * KMAX + cut - 1];
-        if (id_last <= 0) continue;                                    // fewer than `cut` neighbours: nothing beyond the cut
-        const unsigned kc = __shfl(mykey, cut - 1);
-        const int inside = __popcll(__ballot(lane < cut && have && mykey == kc));
-        int all = 0;
-        for (int j = s0 + lane; j < s1; j += 64) all += dkey(j) == kc ? 1 : 0;
+        live[c] = cut <= k && ids[(size_t)i * KMAX + min(cut, KMAX) - 1] > 0;       // fewer than `cut` neighbours: nothing beyond the cut
+        kc[c] = __shfl(mykey, min(cut, 64) - 1);
+        inside[c] = __popcll(__ballot(lane < cut && mine && mykey == kc[c]));
+    }
+    for (int j = s0 + lane; j < s1; j += 64) {
+        const unsigned kj = j == i ? 0xfffffffeu : dkey(j);      // (no key equals this one: the masked flag is the top bit, the rest distance bits)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) all += __shfl_xor(all, o);
-        if (all > inside) out |= 1u << c;
+        for (int c = 0; c < 4; ++c) all[c] += kj == kc[c] ? 1 : 0;
+    }
+    unsigned out = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int a = all[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (live[c] && a > inside[c]) out |= 1u << c;
     }
     if (lane == 0) flags[i] = (unsigned char)out;
 }

@@ -94,6 +94,21 @@ __device__ __forceinline__ void sat_flush_at(float acc, int* __restrict__ flags,
         atomicOr(sc.sflags + (sc.seg_of_atom ? sc.seg_of_atom[row - 1] : sc.frame_n ? (row - 1) / sc.frame_n : 0), 4);
     }
 }
+// conditioning trigger (SatCtx::state_limit): max |new state| of this lane's centre column (8 values of one role's slice) against the limit;
+// seven v_max + a compare per role and 16 centres. The limit is read with the other loads of the finish phase (state_limit_of), well
+// ahead of the compare. NaN compares false: overflow stays the probes' business.
+__device__ __forceinline__ float state_limit_of(const int* __restrict__ flags) {
+    return reinterpret_cast<const SatCtx*>(flags + SATCTX_OFFSET_INTS)->state_limit;
+}
+__device__ __forceinline__ void mag_flush_at(f32x4 a, f32x4 b, float limit, int* __restrict__ flags, int row) {
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))),
+                          fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3]))));
+    if (m > limit && row > 0) {
+        const SatCtx sc = *reinterpret_cast<const SatCtx*>(flags + SATCTX_OFFSET_INTS);
+        atomicOr(flags, 4);
+        atomicOr(sc.sflags + (sc.seg_of_atom ? sc.seg_of_atom[row - 1] : sc.frame_n ? (row - 1) / sc.frame_n : 0), 4);
+    }
+}
 __device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast<const f16x8*>(p); }
 #ifdef PESTO_ABL_NOWL   // ablation: the low weight fragments are not read from LDS (results wrong): -1/3 of the LDS weight traffic
 #define PESTO_WL(fr) ld8h(fr) 
@@ -463,6 +478,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
                 for (int m = 0; m < 2; ++m) st[m] += a[m];
             }
             sat_probe(sat, st[0][0]);
+            if (valid) mag_flush_at(st[0], st[1], state_limit_of(flags), flags, i);
             if (i == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
             if (valid) {
                 float* dst = role == 0 ? q_state + (size_t)i * S : p_state + (size_t)i * 96 + (role - 1) * 32;
@@ -2315,6 +2331,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             // per dependent round trip).
             int cw, cr, ci; bool valid;
             centre_of(tile, fe, cw, cr, ci, valid);
+            const float st_limit = state_limit_of(flags);      // conditioning trigger (with the other loads in front of the rendezvous)
             const float* zr = sm.zrows[cw][0][cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
             const float* fb = W + lw.h_q0 + lane_f * 4;     // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
             f16x8 zh[2], zl[2];
@@ -2380,6 +2397,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                 for (int m = 0; m < 2; ++m) st[m] += b2v[m];
                 sat_probe(sat, st[0][0]);          // (unused columns were fed zeros and the sink row's finite state)
+                if (valid) mag_flush_at(st[0], st[1], st_limit, flags, ci);
                 if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
                 if (valid) { float* dst = q_out + (size_t)ci * S; st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]); }
                 PHASE_MARK(10);
@@ -2428,6 +2446,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                 for (int m = 0; m < 2; ++m) st[m] += h[m];
                 sat_probe(sat, st[0][0]);
+                if (valid) mag_flush_at(st[0], st[1], st_limit, flags, ci);
                 if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
                 if (valid) { float* dst = p_out + (size_t)ci * 96 + (role - 1) * 32; st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]); }
                 PHASE_MARK(10);
@@ -2544,6 +2563,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             const bool valid = cwork < w_end && ci_raw < N1;
             const int ci = valid ? ci_raw : 0;
             const float* zr = sm.zrows[cw][gen][cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
+            const float st_limit = state_limit_of(flags);      // conditioning trigger
             const float* fb = W + lw.h_q0 + lane * 4;       // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
             float* xs = sm.xch + gen * 2048;                // [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column 16][4]
             float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
@@ -2612,6 +2632,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 for (int m = 0; m < 2; ++m) st[m] += h[m];
             }
             sat_probe(sat, st[0][0]);          // (unused columns were fed zeros and the sink row's finite state)
+            if (valid) mag_flush_at(st[0], st[1], st_limit, flags, ci);
             if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
             if (valid) {
                 float* dst = role == 0 ? q_out + (size_t)ci * S : p_out + (size_t)ci * 96 + (role - 1) * 32;

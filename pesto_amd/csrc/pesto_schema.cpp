@@ -6,6 +6,44 @@
 
 namespace pesto {
 
+bool onehot_rows_to_indices(const float* q, int64_t n, int n0, const int* bounds, int n_index, uint8_t* dst) {
+    // branch-free per block so that the compiler vectorises the scans (the rows are read as words: 1.0f = 0x3f800000, +0.0f = 0):
+    // ones = words equal to 1.0f, other = words that are neither 0 nor 1.0f, at = sum of (f - begin) over the ones
+    constexpr uint32_t ONE = 0x3f800000u;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(q) + i * n0;
+        uint32_t lead = 0;
+        for (int f = 0; f < bounds[0]; ++f) lead |= row[f];
+        if (lead) return false;
+        for (int c = 0; c < n_index; ++c) {
+            const int b0 = bounds[c], b1 = bounds[c + 1];
+            int ones = 0, other = 0, at = 0;
+            for (int f = b0; f < b1; ++f) {
+                const int is1 = row[f] == ONE ? 1 : 0;
+                ones += is1;
+                other += (row[f] != 0u && !is1) ? 1 : 0;
+                at += is1 * (f - b0);
+            }
+            if (ones != 1 || other != 0 || at > 255) return false;
+            dst[i * n_index + c] = (uint8_t)at;
+        }
+    }
+    return true;
+}
+
+bool narrow_ids_to_u16(const void* src, int kind, size_t count, uint16_t* dst) {
+    if (kind == 64) {
+        const int64_t* p = static_cast<const int64_t*>(src);
+        uint64_t bad = 0;
+        for (size_t i = 0; i < count; ++i) { bad |= (uint64_t)p[i]; dst[i] = (uint16_t)p[i]; }      // (negative ids set the high bits too)
+        return (bad >> 16) == 0;
+    }
+    const int32_t* p = static_cast<const int32_t*>(src);
+    uint32_t bad = 0;
+    for (size_t i = 0; i < count; ++i) { bad |= (uint32_t)p[i]; dst[i] = (uint16_t)p[i]; }
+    return (bad >> 16) == 0;
+}
+
 bool config_ok(const pesto_config* c) {
     if (!c || c->n0 < 1 || c->n0 > 512 || c->n_layers < 1 || c->n_layers > PESTO_MAX_LAYERS) return false;
     if (c->n_out < 1 || c->n_out > 32) return false;

@@ -102,6 +102,13 @@ struct HostSchema {
     int64_t total = 0;
 };
 
+// ---- host-side packing helpers of pesto_forward_batch_submit (plain C++: pesto_schema.cpp is compiled for the host only)
+// one-hot rows -> byte indices: every block [bounds[c], bounds[c + 1]) of every row of q [n, n0] must hold exactly one 1.0f among +0.0f
+// (encode_features, src/data_encoding.py:78-84) and the columns in front of bounds[0] only zeros; false at the first row that does not
+bool onehot_rows_to_indices(const float* q, int64_t n, int n0, const int* bounds, int n_index, uint8_t* dst);
+// neighbour ids -> uint16 (kind: 32 = int32, 64 = int64): false when an entry is outside [0, 65535] (narrowing must not wrap an invalid id into a valid one)
+bool narrow_ids_to_u16(const void* src, int kind, size_t count, uint16_t* dst);
+
 bool config_ok(const pesto_config* c);
 HostSchema host_schema(const pesto_config& c);
 

@@ -43,6 +43,7 @@ class Model:
         self._cc = _lib.make_c_config(self.config, self.precision)
         self._debug = (0, 0)        # pesto_debug_select(layer_kernels, knn_brute_force): test hook
         self._edge_mode = 0         # pesto_debug_edge_mode: test hook
+        self._state_limit = None    # pesto_set_auto_state_limit (None: library default)
         self._last_device_call = None           # async_auto: tensors of the last device call (kept alive for its deferred check)
         self._blob = None
         self._handle = None
@@ -62,6 +63,23 @@ class Model:
         self._release()
         return "<All keys matched successfully>"
 
+    def load_blob(self, blob):
+        """The weights as the flat float32 blob pesto_create takes (pesto_amd.weights.flatten_state_dict order: the reference's state_dict
+        without m_nn / sdk) - what a rank receives when rank 0 broadcasts the model (sharding.broadcast_weights; SURVEY 8e: ncclBroadcast)."""
+        from .weights import blob_size
+        b = np.ascontiguousarray(blob.detach().cpu().numpy() if _is_torch(blob) else blob, dtype=np.float32).ravel()
+        if b.size != blob_size(self.config):
+            raise ValueError(f"weight blob has {b.size} values, the configuration needs {blob_size(self.config)}")
+        self._blob = b
+        self._release()
+        return self
+
+    def blob(self):
+        """The flat float32 weight blob of the loaded state (see load_blob)."""
+        if self._blob is None:
+            raise RuntimeError("load_state_dict() / load_blob() must be called first")
+        return self._blob
+
     def set_precision(self, precision):
         """"auto" | "f16_split" | "fp32" (pesto_set_precision); takes effect with the next call."""
         code = _lib.precision_code(precision)
@@ -80,6 +98,14 @@ class Model:
             _lib.check(_lib.load().pesto_set_async_auto(self._handle, 1 if self.async_auto else 0))
         if not self.async_auto:
             self._last_device_call = None
+        return self
+
+    def set_auto_state_limit(self, limit):
+        """pesto_set_auto_state_limit: precision "auto" repeats a structure on the exact fp32 kernels once its state magnitude exceeds
+        `limit` in any layer (the split kernels' error is relative to the states); <= 0 switches the trigger off. None = library default."""
+        self._state_limit = None if limit is None else float(limit)
+        if self._handle is not None and self._state_limit is not None:
+            _lib.check(_lib.load().pesto_set_auto_state_limit(self._handle, self._state_limit))
         return self
 
     def status(self):
@@ -179,6 +205,8 @@ class Model:
                 _lib.check(lib.pesto_debug_edge_mode(h, self._edge_mode))
             if self.async_auto:
                 _lib.check(lib.pesto_set_async_auto(h, 1))
+            if getattr(self, "_state_limit", None) is not None:
+                _lib.check(lib.pesto_set_auto_state_limit(h, self._state_limit))
         return self._handle
 
     @property
@@ -365,34 +393,39 @@ class Model:
         Xp, Ip, Qp, Jp, Ap, Zp = (arr(ctypes.c_void_p) for _ in range(6))
         zs, keep = [], []
         host = lambda a: a.detach().cpu().numpy() if _is_torch(a) else np.asarray(a)
-        n_idx_given = sum(1 for s in structures if host(s[2]).dtype == np.uint8)
+        qhs = [host(s[2]) for s in structures]            # (one device-to-host copy per structure when q lives on the GPU - ADVICE r4)
+        n_idx_given = sum(1 for qh in qhs if qh.dtype == np.uint8)
         if n_idx_given not in (0, nb):
             raise ValueError("either every structure passes q as uint8 indices or none does")
         if n_idx_given and offs is None:
             raise ValueError(f"no one-hot feature blocks known for N0 = {n0}")
-        id_dtype = np.uint16 if compact and all(int(np.shape(s[0])[0]) <= 65536 for s in structures) else np.int32
+        # the reference's own forms - bool / float mask M (encode_structure, src/data_encoding.py:61-75), int64 / int32 ids (extract_topology,
+        # :87-102), float one-hot q (encode_features, :78-84) - go to the native layers as they are: the dense mask is reduced by ONE native
+        # pass (libpesto_io, a quarter of the bytes for the bool mask), the ids are narrowed to uint16 and range-checked by the packer's own
+        # copy (PESTO_IDS_NARROW), the one-hot rows are found while they are packed. No numpy pass touches an element here.
+        ids_kinds = set()
         for b, (X, ids, q0, M) in enumerate(structures):
             Mh = host(M)
             if Mh.ndim == 1:                        # res_of_atom given: the library checks its range, the forward that every residue has an atom
                 roa = np.ascontiguousarray(Mh, dtype=np.int32)
                 R = int(roa.max()) + 1 if roa.size else 0
-            elif self.validate:
+            else:
+                # dense mask: always through the checked native reduction (it costs what an unchecked argmax costs; validate=False used to
+                # skip the check to save four numpy passes)
                 roa, R = mask_to_segments(Mh)
                 roa = np.ascontiguousarray(roa, dtype=np.int32)
-            else:
-                roa, R = np.ascontiguousarray(Mh.argmax(1), dtype=np.int32), int(Mh.shape[1])
             Xn = np.ascontiguousarray(host(X), dtype=np.float32)
             idr = host(ids)
-            if idr.dtype != id_dtype:
-                if id_dtype is np.uint16 and idr.size and (int(idr.min()) < 0 or int(idr.max()) > 65535):
-                    # narrowing would wrap an invalid id into a valid one
-                    raise ValueError(f"structure {b}: ids_topk has entries outside [0, N)")
-                idr = idr.astype(id_dtype)
+            if idr.dtype not in (np.int32, np.int64, np.uint16):
+                idr = idr.astype(np.int32)
+            if idr.dtype == np.uint16 and not compact:
+                idr = idr.astype(np.int32)
             idn = np.ascontiguousarray(idr)
+            ids_kinds.add(idn.dtype)
             N = Xn.shape[0]
             if idn.ndim != 2 or idn.shape[0] != N:
                 raise ValueError(f"structure {b}: ids_topk must be [N, k] with N={N}")
-            qh = host(q0)
+            qh = qhs[b]
             if n_idx_given:
                 qn = np.ascontiguousarray(qh)
                 if qn.shape != (N, len(offs)):
@@ -410,7 +443,18 @@ class Model:
         # dense q + block offsets: the library detects one-hot rows while packing (compact only)
         use_offs = offs is not None and (n_idx_given or compact)
         io = (ctypes.c_int32 * 3)(*(list(offs) + [0] * (3 - len(offs)))) if use_offs else None
-        kind = {np.dtype(np.uint16): _lib.IDS_UINT16, np.dtype(np.int32): _lib.IDS_INT32}[np.dtype(id_dtype)]
+        if len(ids_kinds) != 1:      # (mixed tables: one common kind)
+            common = np.dtype(np.int64) if np.dtype(np.int64) in ids_kinds else np.dtype(np.int32)
+            for b in range(nb):
+                Xn, idn, qn, roa = keep[b]
+                if idn.dtype != common:
+                    idn = np.ascontiguousarray(idn.astype(common))
+                    keep[b] = (Xn, idn, qn, roa)
+                    Ip[b] = idn.ctypes.data
+            ids_kinds = {common}
+        kind = {np.dtype(np.uint16): _lib.IDS_UINT16, np.dtype(np.int32): _lib.IDS_INT32, np.dtype(np.int64): _lib.IDS_INT64}[np.dtype(next(iter(ids_kinds)))]
+        if compact and kind != _lib.IDS_UINT16:
+            kind |= _lib.IDS_NARROW
         t = ctypes.c_int32(-1)
         _lib.check(lib.pesto_forward_batch_submit(h, nb, Np, Rp, kp, Xp, Ip, kind, None if n_idx_given else Qp, Jp if n_idx_given else None,
                                                   len(offs) if use_offs else 0, io, Ap, Zp,

@@ -8,6 +8,8 @@ structures (interfaceome/apply_model.py:57-82, apply_model.ipynb:139-167); this 
 torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests) carries only
   * the ragged result gather: per-structure logits z_i [R_i, n_out] (a few KB each), as one all_gather of counts
     and one all_gather of padded payloads,
+  * the weight broadcast at start-up (broadcast_weights: rank 0 reads the checkpoint, every rank builds its handle from the
+    broadcast blob; SURVEY 8e "init: ncclBroadcast(weights)"), checked by a checksum all-gather,
   * barriers / the max-over-ranks timing reduction of bench.py.
 """
 import logging
@@ -253,3 +255,66 @@ def forward_sharded(forward_fn, structures, n_out, max_atoms=24576, group=None, 
     if failed:
         raise AllStructuresFailed(f"every structure of rank(s) {failed} failed (see that rank's log): a systemic problem, not a bad input")
     return out
+
+
+def broadcast_weights(model, state_dict=None, src=0, device=None):
+    """SURVEY 8e "init: ncclBroadcast(weights)": rank ``src`` flattens its state_dict into the weight blob (pesto_amd.weights order), the
+    blob travels through ONE torch.distributed broadcast - a device tensor under nccl (RCCL over xGMI), a host tensor under gloo - and every
+    rank builds its handle from what it received (Model.load_blob); the other ranks need no checkpoint file. All ranks then compare a
+    sha256 of their blob (all_gather_object): a rank that differs raises everywhere. Without a process group: plain load_state_dict.
+    Returns {"bytes", "sha256_16", "ranks_equal", "backend"}."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from .weights import blob_size, flatten_state_dict
+    n = blob_size(model.config)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if state_dict is None:
+            raise ValueError("broadcast_weights: no process group and no state_dict")
+        model.load_state_dict(state_dict)
+        h = hashlib.sha256(model.blob().tobytes()).hexdigest()[:16]
+        return {"bytes": int(n) * 4, "sha256_16": h, "ranks_equal": True, "backend": None}
+    backend = dist.get_backend()
+    rank = dist.get_rank()
+    on_dev = backend == "nccl"
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu"))
+    if rank == src:
+        if state_dict is None:
+            raise ValueError(f"broadcast_weights: rank {src} needs the state_dict")
+        blob = torch.from_numpy(np.ascontiguousarray(flatten_state_dict(model.config, state_dict), dtype=np.float32))
+        t = blob.to(dev) if on_dev else blob
+    else:
+        t = torch.empty(n, dtype=torch.float32, device=dev if on_dev else "cpu")
+    dist.broadcast(t, src=src)
+    model.load_blob(t)
+    h = hashlib.sha256(model.blob().tobytes()).hexdigest()[:16]
+    hs = [None] * dist.get_world_size()
+    dist.all_gather_object(hs, h)
+    if len(set(hs)) != 1:
+        raise RuntimeError(f"broadcast_weights: the ranks hold different weights after the broadcast: {hs}")
+    return {"bytes": int(n) * 4, "sha256_16": h, "ranks_equal": True, "backend": backend}
+
+
+def describe_ranks(device=None):
+    """What the collective library actually sees - for a bench line that must explain itself on hardware nobody could test on:
+    ranks_seen = an all_reduce(SUM) of ones (device tensors under nccl: RCCL carried it), and per rank the device it computes on
+    (name, PCI bus id, device ordinal, host). {"world", "ranks_seen", "backend", "devices": [...]}; without a process group: world 1."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    me = {"rank": 0, "host": socket.gethostname()}
+    if torch.cuda.is_available():
+        d = torch.cuda.current_device() if device is None else torch.device(device).index
+        pr = torch.cuda.get_device_properties(d)
+        me.update({"device": int(d), "device_name": pr.name, "pci_bus_id": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}",
+                   "gcn_arch": getattr(pr, "gcnArchName", None), "hbm_GiB": round(pr.total_memory / 2 ** 30, 1)})
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"world": 1, "ranks_seen": 1, "backend": None, "devices": [me]}
+    backend = dist.get_backend()
+    me["rank"] = dist.get_rank()
+    one = torch.ones(1, dtype=torch.float32, device=(torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else "cpu"))
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    devs = [None] * dist.get_world_size()
+    dist.all_gather_object(devs, me)
+    return {"world": dist.get_world_size(), "ranks_seen": int(round(float(one.item()))), "backend": backend, "devices": devs,
+            "distinct_devices": len({(d_.get("host"), d_.get("pci_bus_id"), d_.get("device")) for d_ in devs})}

@@ -27,7 +27,7 @@ _WIDTH = 16
 ABI_SYMBOLS = [
     "pesto_io_last_error", "pesto_io_read_pdb", "pesto_io_parse_pdb", "pesto_io_from_arrays", "pesto_io_free",
     "pesto_io_preprocess", "pesto_io_n_atoms", "pesto_io_get_xyz", "pesto_io_get_resid", "pesto_io_get_text",
-    "pesto_io_encode", "pesto_io_write_pdb", "pesto_io_format_pdb", "pesto_io_mask_to_segments",
+    "pesto_io_encode", "pesto_io_write_pdb", "pesto_io_format_pdb", "pesto_io_mask_to_segments", "pesto_io_mask_to_segments_any",
 ]
 
 _lib = None
@@ -60,6 +60,7 @@ def load():
     lib.pesto_io_write_pdb.argtypes = [c_p, c_p, i64, ctypes.c_char_p]
     lib.pesto_io_format_pdb.argtypes = [c_p, c_p, i64, P(ctypes.c_char_p), P(i64)]
     lib.pesto_io_mask_to_segments.argtypes = [c_p, i64, i64, c_p]
+    lib.pesto_io_mask_to_segments_any.argtypes = [c_p, ctypes.c_int32, i64, i64, c_p]
     for name in ABI_SYMBOLS:
         if name != "pesto_io_last_error":
             getattr(lib, name).restype = ctypes.c_int

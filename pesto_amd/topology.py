@@ -153,7 +153,7 @@ def mask_to_segments(M):
             raise ValueError("M: empty residue column")
         return torch.argmax(Mb.to(torch.int8), dim=1).to(torch.int32), int(M.shape[1])
     Mh = _np(M)
-    if Mh.ndim == 2 and Mh.dtype == np.float32 and Mh.flags.c_contiguous and Mh.size:
+    if Mh.ndim == 2 and Mh.dtype in (np.float32, np.bool_, np.uint8) and Mh.flags.c_contiguous and Mh.size:
         # one native pass over the rows (libpesto_io.so, host only) instead of four numpy passes over the dense mask: this reduction is
         # the largest host cost per structure of the bulk path when callers hand over the reference's dense M (profiles/r04_host_packing.json)
         try:
@@ -163,7 +163,8 @@ def mask_to_segments(M):
             lib = None
         if lib is not None:
             roa = np.empty(Mh.shape[0], np.int32)
-            if lib.pesto_io_mask_to_segments(Mh.ctypes.data, Mh.shape[0], Mh.shape[1], roa.ctypes.data) != 0:
+            # bool / uint8: the mask as encode_structure returns it (src/data_encoding.py:61-75) - a quarter of the float mask's bytes
+            if lib.pesto_io_mask_to_segments_any(Mh.ctypes.data, Mh.dtype.itemsize, Mh.shape[0], Mh.shape[1], roa.ctypes.data) != 0:
                 raise ValueError(lib.pesto_io_last_error().decode())
             return roa, int(Mh.shape[1])
     Mn = Mh > 0.5

@@ -7,7 +7,7 @@ the pinned staging slot - and queues nothing on the GPU) and pushes the config-4
 bench.py's config-4 leg hands them over, launches of <= 24,576 atoms) through sharding.forward_local for a fixed time. Reported per
 process and in total: structures/s of packing (wall clock), CPU seconds per structure (time.process_time of the process). A second pass
 with the DENSE per-structure forms (float one-hot features, dense residue mask, int32 ids) shows what the library's in-pack one-hot
-detection and the Python-side mask reduction cost."""
+detection and the mask reduction cost (round 5: one native checked pass over the bool / float mask, ids narrowed by the packer)."""
 import json
 import multiprocessing as mp
 import os
@@ -28,14 +28,12 @@ def worker(rank, seconds, dense, q):
     sd, _ = bench.load_weights(cfg)
     m = Model(cfg, validate=False)
     m.load_state_dict(sd)
-    structures, sizes, _ = bench.config4_structures(64, m)           # (GPU k-NN once, outside the timed region)
+    # dense = "native": the reference loader's own per-structure outputs (float32 one-hot q, BOOL mask M, int64 ids:
+    # src/data_encoding.py:61-102); "float": the same with M.float() and int32 ids (round 4's dense row)
+    structures, sizes, _ = bench.config4_structures(64, m, "dense" if dense else "compact")           # (GPU k-NN once, outside the timed region)
+    if dense == "float":
+        structures = [(X, ids.astype(np.int32), q0, M.astype(np.float32)) for X, ids, q0, M in structures]
     if dense:
-        out = []
-        for X, ids, qi, roa in structures:
-            q0 = np.zeros((X.shape[0], 30), np.float32); q0[np.arange(X.shape[0]), qi[:, 0]] = 1.0
-            M = np.zeros((X.shape[0], int(roa.max()) + 1), np.float32); M[np.arange(X.shape[0]), roa] = 1.0
-            out.append((X, ids.astype(np.int32), q0, M))
-        structures = out
         m.validate = True
     m.debug_host_only(True)
     idx = list(range(len(structures)))
@@ -57,7 +55,10 @@ def run(procs, seconds, dense):
     for p in ps:
         p.join()
     rate = [n / w for _, n, w, _ in res]
-    return {"processes": procs, "forms": "dense (float one-hot q, dense mask M, int32 ids; validate=True)" if dense else "compact (uint8 feature indices, res_of_atom, uint16 ids)",
+    forms = {False: "compact (uint8 feature indices, res_of_atom, uint16 ids)",
+             "native": "dense, the reference loader's own outputs (float32 one-hot q, BOOL mask M, int64 ids; validate=True)",
+             "float": "dense with M.float() and int32 ids (float32 one-hot q, float32 mask M; validate=True) - round 4's dense row"}[dense]
+    return {"processes": procs, "forms": forms,
             "structures_per_s_total": float(sum(rate)), "structures_per_s_per_process": [float(r) for r in rate],
             "host_cpu_s_per_structure": float(np.mean([c / n for _, n, _, c in res])),
             "needed_for_8_gpus": 8 * 1700.0}
@@ -66,5 +67,5 @@ def run(procs, seconds, dense):
 if __name__ == "__main__":
     procs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
-    out = {"host_cores": os.cpu_count(), "runs": [run(1, seconds, False), run(procs, seconds, False), run(procs, seconds, True)]}
+    out = {"host_cores": os.cpu_count(), "runs": [run(1, seconds, False), run(procs, seconds, False), run(procs, seconds, "native"), run(procs, seconds, "float")]}
     print(json.dumps(out, indent=1))

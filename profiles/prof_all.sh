@@ -6,7 +6,7 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/trace -o trace --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --no-latency --no-extras --precision f16_split > $R/gpurun_out/$TAG/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/trace -o trace --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-latency --no-extras --precision f16_split > $R/gpurun_out/$TAG/trace.log 2>&1
 cp $(find $R/gpurun_out/$TAG/trace -name "*kernel_stats.csv" | head -1) $R/gpurun_out/$TAG/kernel_stats.csv 2>/dev/null
 cd $R
 bash profiles/pmc_collect.sh $TAG > $R/gpurun_out/$TAG/pmc.log 2>&1
@@ -23,7 +23,7 @@ for row in csv.DictReader(open(stats)):
         tr["k_edge<" + m.group(1).replace(" ", "") + ">"] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
     elif "k_node16" in row["Name"]:
         tr["pesto::k_node16"] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
-t["rocprof_kernel_trace"] = {"kernels": tr, "how": "rocprofv3 --kernel-trace --stats of python bench.py --steps 5 --warmup 2 --precision f16_split "
+t["rocprof_kernel_trace"] = {"kernels": tr, "how": "rocprofv3 --kernel-trace --stats of python bench.py --steps 20 --warmup 5 --precision f16_split "
                                                     "(the same gpurun call as the PMC passes; the profiler adds ~5 % to a launch)"}
 json.dump(t, open(tpath, "w"), indent=1)
 PY

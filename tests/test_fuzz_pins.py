@@ -95,8 +95,33 @@ def test_hip_on_the_two_pinned_inputs(pre, precision):
     err = float(np.abs(z - p["z64"]).max())
     print(f"\n   pinned {pre} {precision}: |hip - reference fp64| {err:.2e}, |hip - reference fp32| {np.abs(z - p['z32']).max():.2e}, "
           f"reference fp32 vs fp64 {np.abs(p['z32'] - p['z64']).max():.2e}, bound {bound(p['z32'], p['z64']):.2e}")
-    assert err <= bound(p["z32"], p["z64"])
+    # round 5: factor ONE on the reference's own fp32-vs-fp64 spread, and the deviation from the reference's fp32 run
+    # itself (8 threads, what a drop-in caller compares with) is asserted, not printed: measured 8.3e-5 / 8.2e-5 and 1.9e-4 / 1.7e-4
+    assert err <= max(1e-4, float(np.abs(p["z32"] - p["z64"]).max()))
+    assert float(np.abs(z - p["z32"]).max()) <= 2e-4
+    assert m.status()["n_fp32_rerun"] == 0          # (state limit at its default: a safety net, these inputs stay below it)
+
+
+@pytest.mark.gpu
+def test_auto_state_limit_repeats_exactly_the_structures_above_it():
+    """pesto_set_auto_state_limit (conditioning trigger of "auto"): with the limit below a structure's state magnitude the structure is
+    repeated on the exact fp32 kernels - its logits equal precision "fp32" bit for bit, the others keep the split kernels' bits; the
+    default (128) fires on none of the pinned / fuzz inputs; <= 0 switches it off."""
+    L = leg_round(0)
+    m = _model()
+    base = m.forward_batch(L["structs"], independent=True)
     assert m.status()["n_fp32_rerun"] == 0
+    exact = _model("fp32").forward_batch(L["structs"], independent=True)
+    m.set_auto_state_limit(32.0)                       # profiles/r05_state_limit.txt: one member of this round exceeds 32 (and 40), none 48
+    z = m.forward_batch(L["structs"], independent=True)
+    n = m.status()["n_fp32_rerun"]
+    assert n == 1
+    hit = [j for j in range(len(z)) if not np.array_equal(z[j], base[j])]
+    assert len(hit) == 1 and np.array_equal(z[hit[0]], exact[hit[0]])
+    m.set_auto_state_limit(0.0)
+    assert all(np.array_equal(a, b) for a, b in zip(m.forward_batch(L["structs"], independent=True), base)) and m.status()["n_fp32_rerun"] == n
+    m.set_precision("f16_split").set_auto_state_limit(1.0)          # f16_split never repeats, so it never flags: no range error either
+    assert all(np.array_equal(a, b) for a, b in zip(m.forward_batch(L["structs"], independent=True), base))
 
 
 @pytest.mark.gpu

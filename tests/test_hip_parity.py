@@ -710,6 +710,7 @@ def test_drop_in_knn_path_on_all_53_chains_ties_are_reported():
         if ci % 9 == 0:
             D = _norm_xyz(X[None, :, :] - X[:, None, :])       # [i, j]
             key = np.where(D < 1e-2, D + 1e9, D)                # masked entries sort behind every other atom, by D among themselves
+            np.fill_diagonal(key, -1.0)                        # the atom itself is no candidate on either side (round 5)
             want = np.zeros(n, np.uint8)
             for c, cut in enumerate((8, 16, 32, 64)):
                 kc = key[np.arange(n), ids[:, cut - 1] - 1]
@@ -774,6 +775,46 @@ def test_config3_i_v3_0_at_n3000():
     roa, R = mask_to_segments(M)
     z = _model("i_v3_0").forward_segments(X, ids0 + 1, q, roa, R)
     assert np.abs(z - gs["z"]).max() < 1e-4
+
+
+def test_softmax_range_is_guarded_not_assumed():
+    """The split kernels evaluate the attention softmax (src/model_operations.py:139-140) as exp2(t) / sum exp2(t) WITHOUT torch's max
+    subtraction: the same function while the logits stay inside the fp32 exponent range (trained checkpoints: -39 .. +64,
+    profiles/r05_logit_range.txt). Outside it the result must never be a plausible wrong number: a centre whose sum overflows or whose
+    every term underflows trips the range guard of its structure - "auto" repeats it on the exact kernels (max-subtracted), "f16_split"
+    fails loudly. Logits are scaled through the last nqm layer of the first state-update layer (Q = nqm(X_n), :119)."""
+    from oracle import oracle
+    from pesto_amd import Model
+    from pesto_amd._lib import ERR_RANGE, PestoError
+    g = golden("fwd_i_v4_0_2CUA")
+    roa = g["res_of_atom"]
+    args = (g["X"], g["ids_topk"].astype(np.int64), onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
+
+    def scaled(f):
+        sd = dict(weights("i_v4_0"))
+        for k in ("sum.0.su.nqm.4.weight", "sum.0.su.nqm.4.bias"):
+            sd[k] = (np.asarray(sd[k]) * np.float32(f)).astype(np.float32)
+        return sd
+    # x4: sharper softmaxes, still far inside the exponent range: no repeat, and the unsubtracted form agrees with the max-subtracted oracle
+    sd4 = scaled(4.0)
+    m = Model(CONFIGS["i_v4_0"]); m.load_state_dict(sd4)
+    z4 = m.forward_segments(*args)
+    assert m.status()["n_fp32_rerun"] == 0
+    z4_ref = oracle.OracleModel(CONFIGS["i_v4_0"], sd4, wide=True).forward_segments(args[0], args[1], args[2], roa, args[4])
+    assert np.abs(z4 - z4_ref).max() < 1e-4, np.abs(z4 - z4_ref).max()
+    # x400: logits of several hundred - exp2 overflows (or every term of a row flushes): flagged, repeated, equal to the exact kernels
+    sd400 = scaled(400.0)
+    m = Model(CONFIGS["i_v4_0"]); m.load_state_dict(sd400)
+    z_auto = m.forward_segments(*args)
+    assert np.isfinite(z_auto).all() and m.status()["n_fp32_rerun"] == 1
+    z_fp32 = m.set_precision("fp32").forward_segments(*args)
+    assert np.array_equal(z_auto, z_fp32)
+    z_ref = oracle.OracleModel(CONFIGS["i_v4_0"], sd400, wide=True).forward_segments(args[0], args[1], args[2], roa, args[4])
+    assert np.abs(z_auto - z_ref).max() < 1e-3, np.abs(z_auto - z_ref).max()      # (saturated softmaxes: near-ties cost more than 1e-4)
+    m.set_precision("f16_split")
+    with pytest.raises(PestoError) as e:
+        m.forward_segments(*args)
+    assert e.value.code == ERR_RANGE
 
 
 def test_trained_i_v3_1_range_guard():

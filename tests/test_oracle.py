@@ -11,8 +11,10 @@ from pesto_amd.weights import blob_size
 from oracle import oracle
 
 
-def _model(tag):
-    return oracle.OracleModel(CONFIGS[tag], weights(tag))
+def _model(tag, wide=False):
+    """wide: the build with double accumulators (float32 storage): the checker the GPU tests use on ill-conditioned inputs - pinned on the
+    same goldens as the plain build (smaller item 10)."""
+    return oracle.OracleModel(CONFIGS[tag], weights(tag), wide=wide)
 
 
 def test_blob_size_matches_python_schema():
@@ -59,26 +61,29 @@ def test_stage_pool_decode():
     ("i_v4_0", "edge_n40"), ("i_v4_0", "edge_batch2"), ("i_v4_0", "edge_coincident"),
     ("i_v4_0", "edge_single_atom_residue"),
 ])
-def test_forward_real_weights(tag, fixture):
+@pytest.mark.parametrize("wide", [False, True])
+def test_forward_real_weights(tag, fixture, wide):
     g = golden(fixture)
-    m = _model(tag)
+    m = _model(tag, wide)
     roa = g["res_of_atom"]
     z = m.forward_segments(g["X"], g["ids_topk"], onehot(g["q_idx"], CONFIGS[tag]["em"]["N0"]), roa, int(roa.max()) + 1)
     assert z.shape == g["z"].shape
     assert np.abs(z - g["z"]).max() < 1e-4
 
 
-def test_forward_i_v4_0_2AYO_config1():
+@pytest.mark.parametrize("wide", [False, True])
+def test_forward_i_v4_0_2AYO_config1(wide):
     g = golden("fwd_i_v4_0_2AYO")
-    m = _model("i_v4_0")
+    m = _model("i_v4_0", wide)
     roa = g["res_of_atom"]
     z = m.forward_segments(g["X"], g["ids_topk"], onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)
     assert np.abs(z - g["z"]).max() < 1e-4
 
 
-def test_forward_i_v4_1_architecture_stacked():
+@pytest.mark.parametrize("wide", [False, True])
+def test_forward_i_v4_1_architecture_stacked(wide):
     """32-layer i_v4_1 architecture with stacked i_v4_0 weights, real geometry (2CUA) and synthetic N=512."""
-    m = _model("i_v4_1")
+    m = _model("i_v4_1", wide)
     g = golden("fwd_i_v4_0_2CUA")
     roa = g["res_of_atom"]
     z = m.forward_segments(g["X"], g["ids_topk"], onehot(g["q_idx"], 30), roa, int(roa.max()) + 1)

@@ -86,6 +86,46 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
             assert got[str(i)].shape == (structures[i][3].shape[1], 5)
 
 
+def _bcast_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from pesto_amd import Model
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        m = Model(CONFIGS["i_v4_0"])                                  # (no handle is built: there is no GPU here)
+        info = sharding.broadcast_weights(m, weights("i_v4_0") if rank == 0 else None, src=0)      # only rank 0 holds a checkpoint
+        ranks = sharding.describe_ranks()
+        np.savez(os.path.join(out_dir, f"b{rank}.npz"), blob=m.blob(), sha=np.array(info["sha256_16"]), seen=ranks["ranks_seen"],
+                 world=ranks["world"], equal=info["ranks_equal"], order=np.array([d["rank"] for d in ranks["devices"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weights_are_broadcast_from_rank0_and_checked(tmp_path):
+    """SURVEY 8e "init: ncclBroadcast(weights)": rank 0 alone has the state_dict; every rank ends with the same blob (checksum all-gathered),
+    which is the blob load_state_dict builds; describe_ranks counts the ranks through an all_reduce (gloo here, RCCL on the GPU box)."""
+    import torch.multiprocessing as mp
+    from pesto_amd.weights import flatten_state_dict
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_bcast_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = np.ascontiguousarray(flatten_state_dict(CONFIGS["i_v4_0"], weights("i_v4_0")), dtype=np.float32)
+    for rank in range(2):
+        g = np.load(os.path.join(str(tmp_path), f"b{rank}.npz"))
+        assert np.array_equal(g["blob"], want) and int(g["seen"]) == 2 and int(g["world"]) == 2 and bool(g["equal"])
+        assert list(g["order"]) == [0, 1]
+    assert str(np.load(os.path.join(str(tmp_path), "b0.npz"))["sha"]) == str(np.load(os.path.join(str(tmp_path), "b1.npz"))["sha"])
+    # without a process group: plain load_state_dict, same blob
+    from pesto_amd import Model
+    m = Model(CONFIGS["i_v4_0"])
+    info = sharding.broadcast_weights(m, weights("i_v4_0"))
+    assert np.array_equal(m.blob(), want) and info["backend"] is None
+    with pytest.raises(ValueError):
+        Model(CONFIGS["i_v4_0"]).load_blob(want[:-1])
+
+
 def test_failed_structure_is_skipped_not_fatal():
     structures = _structures()[:3]
     calls = {"n": 0}
@@ -249,7 +289,7 @@ def test_bench_launcher_two_ranks_on_one_gpu():
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-gpu", "--backend", "gloo", "--steps", "2", "--warmup", "1",
-           "--cpu-budget", "0", "--no-latency", "--config4-structures", "8"]
+           "--cpu-budget", "0", "--no-latency", "--config4-structures", "8", "--strong-structures", "24"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -261,3 +301,29 @@ def test_bench_launcher_two_ranks_on_one_gpu():
     assert c4["structures"] == 16 and c4["bitwise_equal_to_world1"] is True and c4["parity_max_abs_vs_reference"] < 1e-4
     assert len(c4["per_rank"]) == 2 and sum(r["structures"] for r in c4["per_rank"]) == 16
     assert "cpu_baseline" not in out          # (rank 0 at N = 1 only)
+    # round 5: the line explains itself - what the collective library saw, where the weights came from, the reference-native input forms
+    # and the FIXED-list leg SURVEY 8e's acceptance is about
+    assert out["rccl_ranks_seen"] == 2 and out["ranks"]["world"] == 2 and out["ranks"]["backend"] == "gloo"
+    assert [d["rank"] for d in out["ranks"]["devices"]] == [0, 1] and all("device_name" in d and "pci_bus_id" in d for d in out["ranks"]["devices"])
+    wb = out["weights_broadcast"]
+    assert wb["ranks_equal"] is True and wb["backend"] == "gloo" and wb["bytes"] > 5_000_000 and len(wb["sha256_16"]) == 16
+    assert "pre-reduced OUTSIDE" in c4["inputs"]
+    dn = c4["dense_forms"]
+    assert dn["structures"] == 16 and dn["bitwise_equal_to_world1"] is True and dn["parity_max_abs_vs_reference"] < 1e-4 and "INSIDE the timed region" in dn["inputs"]
+    cs = out["config4_strong"]
+    assert cs["structures"] == 24 and cs["bitwise_equal_to_world1"] is True and cs["speedup_vs_world1"] > 0 and cs["scaling"].startswith("strong")
+
+
+def test_bench_prints_one_json_error_line_instead_of_a_traceback():
+    """A failure anywhere before the result line (here: no GPU visible to the process) must still give the driver ONE parseable JSON line
+    on stdout - with "error" and the stage that failed - and a non-zero exit code; the traceback goes to stderr."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""; env["CUDA_VISIBLE_DEVICES"] = ""; env["ROCR_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--cpu-budget", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert p.returncode != 0 and len(lines) == 1, (p.returncode, p.stdout[-500:])
+    out = json.loads(lines[0])
+    assert out["value"] is None and "error" in out and out["error_stage"] == "device check" and out["n_gpus"] == 1

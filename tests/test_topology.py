@@ -98,6 +98,11 @@ def test_mask_to_segments_native_pass_equals_the_numpy_contract():
         assert Rg == R and got.dtype == np.int32 and np.array_equal(got, roa)
         got64, _ = mask_to_segments(M.astype(np.float64))          # (the numpy path: other dtypes / layouts)
         assert np.array_equal(got64, roa)
+        for Mb in (M > 0.5, (M > 0.5).astype(np.uint8)):            # the mask as encode_structure returns it (bool), and as bytes
+            gotb, Rb = mask_to_segments(Mb)
+            assert Rb == R and gotb.dtype == np.int32 and np.array_equal(gotb, roa)
+        Ms = np.ascontiguousarray(M[np.argsort(roa, kind="stable")])      # contiguous residues (the reference's layout): the hinted fast path
+        assert np.array_equal(mask_to_segments(Ms)[0], np.sort(roa)) and np.array_equal(mask_to_segments(Ms > 0.5)[0], np.sort(roa))
     M = np.zeros((6, 3), np.float32); M[np.arange(6), [0, 1, 2, 0, 1, 2]] = 1.0
     for bad in ("two", "none", "empty"):
         Mb = M.copy()
@@ -111,3 +116,11 @@ def test_mask_to_segments_native_pass_equals_the_numpy_contract():
             mask_to_segments(Mb)
         with pytest.raises(ValueError):
             mask_to_segments(Mb.astype(np.float64))
+        with pytest.raises(ValueError):
+            mask_to_segments(Mb > 0.5)
+    # float rows the integer word sums cannot vouch for take the element-wise contract (> 0.5): 0.75 is a member, -0.0 and 0.25 are not
+    Mo = np.zeros((3, 3), np.float32); Mo[0, 0] = 0.75; Mo[1, 1] = 1.0; Mo[1, 2] = -0.0; Mo[2, 2] = 1.0; Mo[2, 0] = 0.25
+    assert np.array_equal(mask_to_segments(Mo)[0], [0, 1, 2])
+    Mo[2, 0] = 0.6
+    with pytest.raises(ValueError):
+        mask_to_segments(Mo)
