@@ -69,6 +69,8 @@ struct pesto_model {
     int64_t n_forward = 0, n_rerun = 0;    // launch sequences run / STRUCTURES repeated on the exact fp32 kernels after a range overflow
     DevBuf sflags;                         // range guard: one word per structure (frame) of the launch (SatCtx)
     std::vector<int> h_sflags;             // host copy (counting the structures a repeat covers)
+    hipEvent_t ev_flags = nullptr;         // recorded behind the early copy of the flags word (run_forward): AUTO's check does not wait for the pool kernels
+    bool early_flags = false;              // that copy was queued by the last run_forward (h_flags[4] holds it once ev_flags has fired)
     std::vector<int> knn_off_host;         // the structure offsets knn_off holds on the device (pesto_knn_collate / pesto_knn_tie_rows)
     float state_limit = PESTO_AUTO_STATE_LIMIT_DEFAULT;   // pesto_set_auto_state_limit: conditioning trigger of AUTO (SatCtx::state_limit)
     bool async_auto = false;               // pesto_set_async_auto: device-pointer calls under AUTO defer their check to the next call
@@ -147,7 +149,8 @@ int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
         rc |= m->rec_nb.ensure(N1 * REC_NB * sizeof(float));
         rc |= m->rec_cen.ensure(N1 * REC_CEN * sizeof(float));
         rc |= m->rec_nb2.ensure(N1 * REC_A * sizeof(float));
-        rc |= m->zrec.ensure(N1 * REC_Z * sizeof(float));
+        // (also the edge kernel's operand stash: one 2 KB slot per tile of a wave's work item, 256 workgroups x 12 waves x 4 tiles)
+        rc |= m->zrec.ensure(std::max((size_t)N1 * REC_Z * sizeof(float), (size_t)EDGE_STASH_BYTES));
     }
     return rc ? fail(PESTO_ERR_NOMEM, "device workspace allocation failed for N=%lld R=%lld", (long long)N, (long long)R) : 0;
 }
@@ -179,10 +182,17 @@ struct Sequence {      // every entry point that touches the workspace holds one
 };
 
 // synchronises st; *flag_out (optional) receives the flags word: bit 0 bad ids, bit 1 bad residue column, bit 2 f16-range overflow
-int check_device_flag(pesto_model* m, hipStream_t st, int* flag_out = nullptr, int ignore = 0) {
-    HIP_TRY(hipMemcpyAsync(m->h_flags, err_ptr(m), sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const int flag = *m->h_flags;
+// early: the launch sequence just queued copied its (final) flags word in front of its pool kernels (run_forward): wait for that copy only
+int check_device_flag(pesto_model* m, hipStream_t st, int* flag_out = nullptr, int ignore = 0, bool early = false) {
+    int flag;
+    if (early && m->early_flags) {
+        HIP_TRY(hipEventSynchronize(m->ev_flags));
+        flag = m->h_flags[4];
+    } else {
+        HIP_TRY(hipMemcpyAsync(m->h_flags, err_ptr(m), sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        flag = *m->h_flags;
+    }
     if (flag_out) *flag_out = flag;
     if (flag & 1) return fail(PESTO_ERR_INVALID, "ids_topk contains an index outside [0, N]");
     if (flag & 2) return fail(PESTO_ERR_INVALID, "res_of_atom contains an index outside [0, R) (from pesto_mask_to_segments: a row of M with != 1 member or an empty residue column)");
@@ -294,10 +304,10 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
         for (int l = 0; l < L; ++l) {
             HIP_TRY(mark(nn_class(m->cfg.nn[l])));
 #ifdef PESTO_ABL_NOPREP      // timing-only ablation: no prepare phase (every layer reads the first layer's records)
-            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), rnb[0], rcen, p[cur], nullptr, m->edge_blocks,
+            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), rnb[0], rcen, p[cur], m->zrec.as<float>(), m->edge_blocks,
                         edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1], nullptr, rnb[1], rcen,
 #else
-            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), rnb[cur], rcen, p[cur], nullptr, m->edge_blocks,
+            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), rnb[cur], rcen, p[cur], m->zrec.as<float>(), m->edge_blocks,
                         edge_variant, err_ptr(m), q[cur], q[cur ^ 1], p[cur ^ 1],
                         l + 1 < L ? &m->img.layers[l + 1] : nullptr, rnb[cur ^ 1], rcen,
 #endif
@@ -332,6 +342,17 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
         m->n_layer_launches = m->impl != 2 ? m->cfg.n_layers : (edge_variant == 0 && m->edge_mode < 4) ? m->cfg.n_layers + 1 : 2 * m->cfg.n_layers + 1;
         m->have_timing = true;
     }
+    // The flags word is FINAL here: bad ids / residue columns are found by the unpack (and frame-expansion) launches, the range guard fires
+    // in the layer kernels; the pool kernels only read it (they are fp32: nothing in them can overflow). AUTO's check of a device-pointer
+    // call therefore waits for THIS copy, not for the stream: the host gets its answer while the pool kernels still run and the next
+    // call's launches queue up behind them - no idle gap between two one-structure forwards (round 5, batch-1 latency).
+    m->early_flags = false;
+    if (!exact && !masked && m->precision == PESTO_PRECISION_AUTO) {
+        if (!m->ev_flags) HIP_TRY(hipEventCreateWithFlags(&m->ev_flags, hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(m->h_flags + 4, err_ptr(m), sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(m->ev_flags, st));
+        m->early_flags = true;
+    }
     launch_pool(st, m->W, m->img.model, m->cfg.n_out, (int)NT, (int)RT, q[cur] + S, p[cur] + 96, roa, m->pool_a.as<float>(),
                 seg_lo, seg_hi, err_ptr(m), nullptr, nullptr, a.z_out, bounds_in_embed, sc, masked);
     HIP_TRY(hipGetLastError());
@@ -365,7 +386,7 @@ int rerun_flagged(pesto_model* m, hipStream_t st, const FwdArgs& a) {
 //   defer     : AUTO with device pointers on a handle with pesto_set_async_auto(m, 1): no synchronisation, the check is made by the
 //               next call on the handle (resolve_pending).
 template <typename AfterRun>
-int forward_policy(pesto_model* m, hipStream_t st, const FwdArgs& a, bool sync_check, AfterRun after_run, bool defer = false) {
+int forward_policy(pesto_model* m, hipStream_t st, const FwdArgs& a, bool sync_check, AfterRun after_run, bool defer = false, bool device_call = false) {
     const bool exact_first = m->precision == PESTO_PRECISION_FP32 || m->impl != 2;
     if (int rc = run_forward(m, st, a, exact_first)) return rc;
     if (int rc = after_run()) return rc;
@@ -384,7 +405,8 @@ int forward_policy(pesto_model* m, hipStream_t st, const FwdArgs& a, bool sync_c
     if (!sync_check) return 0;
     int flag = 0;
     const bool may_rerun = m->precision == PESTO_PRECISION_AUTO && !exact_first;
-    if (int rc = check_device_flag(m, st, &flag, may_rerun ? 4 : 0)) return rc;
+    // (device-pointer calls have nothing to wait for but the verdict: the early copy; host-pointer calls wait for their D2H anyway)
+    if (int rc = check_device_flag(m, st, &flag, may_rerun ? 4 : 0, device_call && may_rerun)) return rc;
     if ((flag & 4) && may_rerun) {
         if (int rc = rerun_flagged(m, st, a)) return rc;
         if (int rc = after_run()) return rc;
@@ -476,6 +498,7 @@ int pesto_destroy(pesto_model* m) {
     if (m->pend.ev) (void)hipEventDestroy(m->pend.ev);
     delete static_cast<FwdArgs*>(m->pend.args);
     if (m->ws_ev) (void)hipEventDestroy(m->ws_ev);
+    if (m->ev_flags) (void)hipEventDestroy(m->ev_flags);
     if (m->h_flags) (void)hipHostFree(m->h_flags);
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : m->kev) if (e) (void)hipEventDestroy(e);
@@ -661,7 +684,7 @@ int forward_common(pesto_model* m, int64_t N, int64_t R, int32_t k, int64_t n_fr
             // AUTO: checked before the call returns (one 4-byte D2H + a stream synchronisation); on a handle with pesto_set_async_auto the
             // last chunk is left to the next call on the handle instead (every other chunk of a multi-chunk frame call is checked here)
             const bool last = c + 1 == n_chunks;
-            if (int rc = forward_policy(m, st, a, m->precision == PESTO_PRECISION_AUTO, [] { return 0; }, last && m->async_auto)) return rc;
+            if (int rc = forward_policy(m, st, a, m->precision == PESTO_PRECISION_AUTO, [] { return 0; }, last && m->async_auto, true)) return rc;
         }
         return 0;
     }
@@ -1231,7 +1254,7 @@ int pesto_stage_layer(pesto_model* m, int32_t layer, float* q_io, float* p_io) {
         const int ev = m->precision == PESTO_PRECISION_FP32 ? 1 : 0;     // no automatic re-run at stage level
         launch_node(st, m->W, nullptr, L, (int)N1, m->q_a.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), ev, err_ptr(m));
         if (ev == 0) {      // shipped path: the finish phase runs inside the edge kernel, new state in the other buffer pair
-            launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), nullptr, m->edge_blocks, ev, err_ptr(m),
+            launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->edge_blocks, ev, err_ptr(m),
                         m->q_a.as<float>(), m->q_b.as<float>(), m->p_b.as<float>(), nullptr, nullptr, nullptr, m->edge_mode);
         } else {
             launch_edge(st, m->W, *L, (int)N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(), m->rec_cen.as<float>(), m->p_a.as<float>(), m->zrec.as<float>(), m->edge_blocks, ev, err_ptr(m));

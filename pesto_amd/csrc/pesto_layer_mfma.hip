@@ -1636,6 +1636,21 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 
         // ------------------------------------------------------------------ pass 1: keys -> logits (eqkm, epkm)
         constexpr bool ONEP = TI == 1 && !PF && HY;      // one-tile items: see l1_issue_ac
+        // STASH (round 5, measured and NOT shipped; -DPESTO_STASH_OPERAND builds it): items of several tiles cannot keep the first pass's
+        // p_j . r_hat operand (hi, lo: eight registers per tile) until the second pass, and the LDS is full - the second pass gathers the
+        // six p_j pieces again, recomputes the projection, splits it and moves it to the MFMA lanes (27 packed VALU + 12 split + 8
+        // ds_bpermute + 6 gathers per tile). The variant parks the finished operand in a per-wave slot of global memory (2 KB per tile, two
+        // coalesced 16-byte stores per lane), reads it back in the second pass (an L2 hit) and takes the one-tile items' path. Same bits,
+        // ~70 issue units fewer per tile - and 2.5 - 5.7 % SLOWER on every layer kernel of the forward, including the nn = 8 one that
+        // does not use it (profiles/r05_stash_ab.txt): +390 MB of fabric traffic per nn = 64 launch (233 MB before) costs package power,
+        // and the chip sits at its 1,400 W limit - the clock pays for the bytes.
+#ifdef PESTO_STASH_OPERAND
+        constexpr bool STASH = TI > 1 && !PF && HY && FIN && !M32 && !(NN == 32 && TI == 2);      // (that instantiation spilled 428 B per lane)
+#else
+        constexpr bool STASH = false;
+#endif
+        float* const stash = STASH ? Z + ((size_t)(blockIdx.x * WPB + wave) * TI) * 512 + lane * 4 : nullptr;      // [tile][hi | lo][lane][16 B]
+        (void)stash;
         // W3SPLIT: the part-3 attention weights (the p_j sums' weights) are kept parity-split in LDS and read 16 bytes at a time. Not in the
         // fine-item nn = 32 instantiation (one-structure launches): at the 168-register limit the two live float4 spill there (20 B per
         // lane, +0.7 us per launch, measured in both pairs of profiles/r04_epilogue_ab.txt). Writer and reader share this switch.
@@ -1643,6 +1658,20 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         L1RawAC rac2;
         f16x8 pr_h, pr_l;
         (void)rac2; (void)pr_h; (void)pr_l;
+        // VFIRST (round 5, measured and NOT shipped; -DPESTO_VFIRST builds it): one-tile items run the VALUE network right behind the key
+        // networks, in front of the softmax - the two MLP chains are independent (only the weighted sums need the attention weights), and
+        // a one-tile item is a single dependent chain per wave: with two item waves per SIMD the nn = 8 layer runs at 1.58x its issue
+        // floor (profiles/r05_issue_floor.md). Same operands and MFMA order per accumulator (same bits) - and no gain: nn = 8 58.9 ->
+        // 59.7 us, one structure 0.932 -> 0.939 ms on one box (profiles/r05_vfirst_ab.txt). The compiler keeps the two chains one after the
+        // other; moving a chain in front of the softmax does not shorten anything by itself.
+#ifdef PESTO_VFIRST
+        constexpr bool VFIRST = ONEP && F16 && FIN;
+#else
+        constexpr bool VFIRST = false;
+#endif
+        f32x4 v_first[4];
+        f32x4 pv_first[4];
+        (void)v_first; (void)pv_first;
         {
             // layers 2/3 of the key networks for one tile, raw logits parked in the (not yet used) attention-weight table
             auto keys_of_tile = [&](int t, const f32x4* h1) {
@@ -1757,6 +1786,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         L1Head hd = l1_head<NN>(raw, t, lane, tcc, ws);
                         __builtin_amdgcn_sched_barrier(0);
                         if (ONEP) { rac2 = l1_issue_ac<NN>(4, lane, tcc); pr_h = hd.fh; pr_l = hd.fl; }
+                        if (STASH) {
+                            st4(stash + t * 512, __builtin_bit_cast(f32x4, hd.fh));
+                            st4(stash + t * 512 + 256, __builtin_bit_cast(f32x4, hd.fl));
+                        }
                         if (t < TI - 1) {
                             tcc = tile_ctx<NN, HY>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
                             raw = l1_issue<NN>(0, t + 1, lane, tcc, ws, p_state);
@@ -1768,7 +1801,69 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         __builtin_amdgcn_s_setprio(1);
                         l1_tail(hd, 0, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
                         keys_of_tile(t, h1);
+                        if constexpr (VFIRST) {      // (t == 0: a one-tile item)
+                            L1Head hv = l1_head_ac<NN>(rac2, pr_h, pr_l, lane, tcc);
+                            f32x4 h1v[4];
+                            l1_tail(hv, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1v, sat);
+                            f32x4 acc2v[4];
+#pragma unroll
+                            for (int ml = 0; ml < 4; ++ml) acc2v[ml] = ld4(sm.w + EL_B2 + 64 + 16 * ml + 4 * g);
+#pragma unroll
+                            for (int kgp = 0; kgp < 2; ++kgp) {
+                                f16x8 xh, xl;
+                                split8(h1v[2 * kgp], h1v[2 * kgp + 1], xh, xl);
+#pragma unroll
+                                for (int m0 = 0; m0 < 4; m0 += 2) {
+                                    f16x8 wh[2], wl[2];
+#pragma unroll
+                                    for (int ml = 0; ml < 2; ++ml) {
+                                        const float* fr = w2f + 8 * 256 + (size_t)(((m0 + ml) * 2 + kgp) * 2) * 256 + lane * 4;
+                                        wh[ml] = ld8h(fr); wl[ml] = PESTO_WL(fr);
+                                    }
+#pragma unroll
+                                    for (int ml = 0; ml < 2; ++ml) acc2v[m0 + ml] = MFMA16(wh[ml], xh, acc2v[m0 + ml]);
+#pragma unroll
+                                    for (int ml = 0; ml < 2; ++ml) acc2v[m0 + ml] = MFMA16(wh[ml], xl, acc2v[m0 + ml]);
+#pragma unroll
+                                    for (int ml = 0; ml < 2; ++ml) acc2v[m0 + ml] = MFMA16(wl[ml], xh, acc2v[m0 + ml]);
+                                }
+                            }
+                            sat_probe(sat, acc2v[0][0]);          // h1 of the value net beyond the f16 range
+                            f32x4 h2v[4];
+#pragma unroll
+                            for (int ml = 0; ml < 4; ++ml) h2v[ml] = elu4s(acc2v[ml]);
+#pragma unroll
+                            for (int fo = 0; fo < 4; ++fo) v_first[fo] = ld4(&sm.b3v4[4 * (16 * fo + e)]);
+#pragma unroll
+                            for (int kgp = 0; kgp < 2; ++kgp) {
+                                f16x8 ah, al;
+                                split8(h2v[2 * kgp], h2v[2 * kgp + 1], ah, al);
+#pragma unroll
+                                for (int f0 = 0; f0 < 4; f0 += 2) {
+                                    f16x8 bh[2], bl[2];
+#pragma unroll
+                                    for (int fo = 0; fo < 2; ++fo) {
+                                        const float* fr = w3v + (size_t)(((f0 + fo) * 2 + kgp) * 2) * 256 + lane * 4;
+                                        bh[fo] = ld8h(fr); bl[fo] = PESTO_WL(fr);
+                                    }
+#pragma unroll
+                                    for (int fo = 0; fo < 2; ++fo) v_first[f0 + fo] = MFMA16(ah, bh[fo], v_first[f0 + fo]);
+#pragma unroll
+                                    for (int fo = 0; fo < 2; ++fo) v_first[f0 + fo] = MFMA16(al, bh[fo], v_first[f0 + fo]);
+#pragma unroll
+                                    for (int fo = 0; fo < 2; ++fo) v_first[f0 + fo] = MFMA16(ah, bl[fo], v_first[f0 + fo]);
+                                }
+                            }
+                        }
                         __builtin_amdgcn_s_setprio(0);
+                        if constexpr (VFIRST) {      // the first half of the tile's p_j gathers for the part-3 sums: in flight during the softmax
+                            const int esub0 = lane >> 5, quad0 = (lane & 31) < 24 ? (lane & 31) : (lane & 31) - 24;
+                            int nbj[4];
+#pragma unroll
+                            for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[2 * i2 + (esub0 & 1)]);
+#pragma unroll
+                            for (int i2 = 0; i2 < 4; ++i2) pv_first[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad0);
+                        }
                     }
                     if (SAT2) { const float tmp = sat; sat = sat_b; sat_b = tmp; }      // sat: first centre again, sat_b: second
                 }
@@ -1925,15 +2020,28 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             // so that the fold over the parities is a half swap)
             const int esub = EPI2 ? lane >> 5 : lane / 24, quad = EPI2 ? ((lane & 31) < 24 ? (lane & 31) : (lane & 31) - 24) : lane - 24 * esub;
             f32x4 pv[4];
-            {
+            if constexpr (VFIRST) {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) pv[i2] = pv_first[i2];
+            } else {
                 int nbj[4];
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 2 * i2 + (esub & 1)]);
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
             }
+            f32x4 pvB[4];
+            (void)pvB;
+            if constexpr (VFIRST) {      // second half of the tile's edges, requested at once (no value network to hide them behind)
+                int nbj[4];
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)]);
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) pvB[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
+            }
             f32x4 h1[4];
-            if (PF) {
+            if constexpr (VFIRST) {
+            } else if (PF) {
 #pragma unroll
                 for (int fbl = 0; fbl < 4; ++fbl)
                     h1[fbl] = l1_compute<NN>(pre[fbl], 4 + fbl, g, tc.bgA, tc.bgB, sm.w + EL_WD, tc.d, tc.rx, tc.ry, tc.rz);
@@ -1941,6 +2049,11 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 L1Head hd;
                 if (ONEP) {
                     hd = l1_head_ac<NN>(rac2, pr_h, pr_l, lane, tc);
+                } else if (STASH) {
+                    const L1RawAC rac = l1_issue_ac<NN>(4, lane, tc);
+                    const f32x4 sh = ld4(stash + t * 512), sl = ld4(stash + t * 512 + 256);
+                    __builtin_amdgcn_sched_barrier(0);
+                    hd = l1_head_ac<NN>(rac, __builtin_bit_cast(f16x8, sh), __builtin_bit_cast(f16x8, sl), lane, tc);
                 } else {
                     const L1Raw raw = l1_issue<NN>(4, t, lane, tc, ws, p_state);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1971,6 +2084,13 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            f32x4 v[4];
+            if constexpr (VFIRST) {
+#pragma unroll
+                for (int fo = 0; fo < 4; ++fo) v[fo] = v_first[fo];
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) pv[i2] = pvB[i2];
+            } else {
             f32x4 acc2[4];
 #pragma unroll
             for (int ml = 0; ml < 4; ++ml) acc2[ml] = ld4(sm.w + EL_B2 + 64 + 16 * ml + 4 * g);
@@ -2019,7 +2139,6 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
             for (int ml = 0; ml < 4; ++ml) h2[ml] = F16 ? elu4s(acc2[ml]) : elu4(acc2[ml]);
             // V[edge 16t + 4g + r][feature 16fo + e]: edges as rows (A operand = h2), weights as B operand
-            f32x4 v[4];
 #pragma unroll
             for (int fo = 0; fo < 4; ++fo) {
                 if constexpr (HY && !M32) {
@@ -2063,6 +2182,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         for (int fo = 0; fo < 4; ++fo) v[fo] = MFMA(h2[ml][r], wv[fo][r], v[fo]);
                 }
             }
+            }      // !VFIRST
             PHASE_MARK(4);
             __builtin_amdgcn_s_setprio(0);
             if constexpr (W3SPLIT) {
@@ -2577,6 +2697,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     split8(a0, a1, zh[kgp], zl[kgp]);
                 }
                 lds_signal(&sm.xflag[XF_CONSUMED], lane == 0);
+#ifdef PESTO_NODEW_PRIO      // (developer: priority of a node wave while it computes; it polls at priority 0)
+                __builtin_amdgcn_s_setprio(PESTO_NODEW_PRIO);
+#endif
             };
             auto post = [&](const f32x4* v) {
                 st4(xs + ((2 * role) * 4 + fg) * 64 + fe * 4, v[0]);
@@ -2749,6 +2872,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #undef PESTO_FIN_MFMA
             if (valid) sat_flush_at(sat, flags, ci);      // (the probes of a node wave are MFMA column fe = centre ci)
             sat = 0.0f;
+#ifdef PESTO_NODEW_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         ++fin_iter;
       }
