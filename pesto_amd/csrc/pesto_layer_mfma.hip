@@ -2993,7 +2993,7 @@ static double rounds_paid(int n_work, int waves, int subs) {
 }
 static bool node_wave_mode(int nn, int n_work) {
     const int subs = nn == 64 ? 2 : 1;                                     // items per wave and iteration (two staged centres per wave)
-    const double cost = nn == 8 ? 0.90 : nn == 16 ? 0.965 : nn == 32 ? 0.985 : 1.023;      // (nn = 32 re-measured in round 3: 158.5 vs 160.8-165 us at 8 x 3,000 atoms)
+    const double cost = nn == 8 ? 0.87 : nn == 16 ? 0.94 : nn == 32 ? 0.985 : 1.023;      // (nn = 8 / 16 re-measured in round 5: 56.1 vs 66.9, 86.1 vs 91.6 us)      // (nn = 32 re-measured in round 3: 158.5 vs 160.8-165 us at 8 x 3,000 atoms)
     return rounds_paid(n_work, 8, subs) * cost < rounds_paid(n_work, 12, subs);
 }
 // M32: the 32-edge-tile kernel (v_mfma_f32_32x32x16_f16, eight-wave rendezvous workgroups); its gathers use 32-bit buffer offsets
@@ -3018,13 +3018,17 @@ static bool launch_edge_m32_unfused(hipStream_t st, const float* W, const LayerW
 }
 static void launch_edge_full(hipStream_t st, const float* W, const LayerW& lw, int N1, const EdgeIO& io, int max_blocks, int mode) {
     if (mode == 3 && launch_edge_m32(st, W, lw, N1, io, max_blocks)) return;
-    const int a = lw.nn == 64 ? 1 : 2;                                     // centres per 64-row item (nn = 8: one-tile items of two centres)
+    const int a = lw.nn == 64 ? 1 : 2;                                     // centres per wave and work step (nn = 8: one-tile items of two centres; nn = 16 node-wave mode: two one-centre items)
     const bool nw = mode == 0 ? node_wave_mode(lw.nn, (N1 + a - 1) / a) : mode == 2;
     switch (lw.nn) {
         case 8: if (nw) launch_edge_k<8, 12, false, true, true, 1, true, 8>(st, W, lw, N1, io, max_blocks);
                 else launch_edge_k<8, 12, false, true, true, 1, true>(st, W, lw, N1, io, max_blocks);
                 break;
-        case 16: if (nw) launch_edge_k<16, 12, false, true, true, 2, true, 8>(st, W, lw, N1, io, max_blocks);
+        // nn = 16, node-wave mode (round 5): ONE-tile items, two per wave and iteration, instead of one two-tile item - a one-tile item reuses
+        // the first pass's p_j . r_hat operand in the second pass (ONEP: no second gather of the six p_j pieces, no second projection, split
+        // and lane move), which a two-tile item cannot (no registers to keep two operands). Same bits (the fine-item kernels of small
+        // launches are this instantiation); same box 90.3 -> 86.1 us per launch (profiles/r05_nn16_onetile_ab.txt).
+        case 16: if (nw) launch_edge_k<16, 12, false, true, true, 1, true, 8>(st, W, lw, N1, io, max_blocks);
                  else launch_edge_k<16, 12, false, true, true, 2, true>(st, W, lw, N1, io, max_blocks);
                  break;
         case 32: if (nw) launch_edge_k<32, 12, false, true, true, 4, true, 8>(st, W, lw, N1, io, max_blocks);
