@@ -94,9 +94,11 @@ def main():
         out.append(run(f"i_v4_1 stacked {d['names'][i].decode()}", m1, *chain_inputs(d, i, 30)))
     g = np.load(os.path.join(HERE, "fuzz_pins.npz"))
     print(g.files)
-    open(os.path.join(ROOT, "profiles", "r05_logit_range.txt"), "w").write(
-        "# attention logits of the reference's softmaxes (tests/golden/probe_logits.py, build container): the kernel's exp2 without max subtraction\n"
-        "# is exact-equivalent while |logit| << 88; its guard flags a structure at |logit| > 60 (DESIGN 4.1h)\n" + "\n".join(out) + "\n")
+    hdr = ("# attention logits of the REFERENCE's softmaxes (tests/golden/probe_logits.py: the reference imported in the build container,\n"
+           "# torch.nn.functional.softmax patched to record its inputs). 'row maxima' = smallest and largest per-row maximum over the attention\n"
+           "# softmaxes of a forward (max|logit| ~ 1e6 is the pool layer's -1e6 mask, src/model_operations.py:199). The kernel's exp2 / sum without max\n"
+           "# subtraction needs them inside fp32's exponent range and guards that per centre (DESIGN 4.1h).\n")
+    open(os.path.join(ROOT, "profiles", "r05_logit_range.txt"), "w").write(hdr + "\n".join(out) + "\n")
 
 
 if __name__ == "__main__":
