@@ -115,6 +115,13 @@ int pesto_set_async_auto(pesto_model* m, int32_t enabled);
  * logits with the trigger off; a caller that wants the exact kernels on such inputs sets a lower limit or PESTO_PRECISION_FP32.) */
 #define PESTO_AUTO_STATE_LIMIT_DEFAULT 128.0f
 int pesto_set_auto_state_limit(pesto_model* m, float limit);
+/* Second conditioning trigger of PESTO_PRECISION_AUTO, on by default: a structure with ZERO-PADDED neighbour slots - fewer than 64 atoms,
+ * or a table of fewer than 64 columns (collate_batch_features pads with 0, src/dataset.py:100-109; unpack_state_features wraps those slots
+ * to the last atom, src/model_operations.py:8) - is repeated on the exact fp32 kernels. Padded slots are where the forward is
+ * ill-conditioned for any fp32 evaluation (the reference's own fp32 and fp64 runs differ by 1.15e-4 on the pinned 2-atom member of
+ * tests/golden/fuzz_pins.npz; the split kernels by 0.8 - 1.4e-4 depending on summation order, the exact kernels by 2e-5); real structures
+ * have none, so the repeat costs nothing where throughput matters. enabled == 0 switches it off. F16_SPLIT / FP32 ignore it. */
+int pesto_set_auto_pad_trigger(pesto_model* m, int32_t enabled);
 
 /* replaces: Model.forward(X, ids_topk, q0, M)  (model/model.py:32-52).
  * ptr_kind: PESTO_PTR_HOST (library stages H2D/D2H itself) or PESTO_PTR_DEVICE (all five buffers on

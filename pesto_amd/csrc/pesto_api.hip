@@ -72,6 +72,7 @@ struct pesto_model {
     hipEvent_t ev_flags = nullptr;         // recorded behind the early copy of the flags word (run_forward): AUTO's check does not wait for the pool kernels
     bool early_flags = false;              // that copy was queued by the last run_forward (h_flags[4] holds it once ev_flags has fired)
     std::vector<int> knn_off_host;         // the structure offsets knn_off holds on the device (pesto_knn_collate / pesto_knn_tie_rows)
+    bool pad_trigger = true;               // pesto_set_auto_pad_trigger: AUTO repeats structures with zero-padded neighbour slots on the exact kernels (SatCtx::pad_trigger)
     float state_limit = PESTO_AUTO_STATE_LIMIT_DEFAULT;   // pesto_set_auto_state_limit: conditioning trigger of AUTO (SatCtx::state_limit)
     bool async_auto = false;               // pesto_set_async_auto: device-pointer calls under AUTO defer their check to the next call
     // every launch sequence uses the ONE workspace below: sequences on different streams are ordered through this event
@@ -239,7 +240,8 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
     if (m->dmax.ensure(clear_bytes) || m->sflags.ensure(n_dmax * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
     // conditioning trigger: only where a flagged structure is repeated (AUTO on the split kernels); f16_split never repeats, so it never flags
     const float state_limit = (!exact && m->precision == PESTO_PRECISION_AUTO && m->state_limit > 0.0f) ? m->state_limit : __builtin_huge_valf();
-    const SatCtx sc{err_ptr(m), m->sflags.as<int>(), a.seg_of_atom, (!a.seg_of_atom && a.F > 1) ? (int)a.N : 0, state_limit};
+    const SatCtx sc{err_ptr(m), m->sflags.as<int>(), a.seg_of_atom, (!a.seg_of_atom && a.F > 1) ? (int)a.N : 0, state_limit,
+                    (!exact && m->precision == PESTO_PRECISION_AUTO && m->pad_trigger) ? 1 : 0};
     int* seg_lo = m->dmax.as<int>() + seg_off;
     int* seg_hi = seg_lo + RT;
     const bool bounds_in_embed = a.F == 1;             // found by the unpack launch (trajectory batches expand res_of_atom per frame behind it: separate launches)
@@ -549,6 +551,13 @@ int pesto_set_auto_state_limit(pesto_model* m, float limit) {
     if (limit != limit) return fail(PESTO_ERR_INVALID, "state limit must be a number (<= 0 switches the trigger off)");
     if (int rc = resolve_pending(m)) return rc;
     m->state_limit = limit;
+    return 0;
+}
+
+int pesto_set_auto_pad_trigger(pesto_model* m, int32_t enabled) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(m)) return rc;
+    m->pad_trigger = enabled != 0;
     return 0;
 }
 

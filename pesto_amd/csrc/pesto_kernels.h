@@ -21,7 +21,13 @@ struct ClearArgs { int* p0 = nullptr; int n0 = 0; int* p1 = nullptr; int n1 = 0;
 // term is 2^-22 RELATIVE, so its absolute error grows with the states. A finishing wave that sees max |new state| of a centre above the
 // limit sets the SAME guard bit as an overflow: the structure is repeated on the exact kernels. +inf (precision f16_split / fp32, or the
 // trigger switched off) = never.
-struct SatCtx { int* flags = nullptr; int* sflags = nullptr; const int* seg_of_atom = nullptr; int frame_n = 0; float state_limit = __builtin_huge_valf(); };
+// pad_trigger (round 5): a structure with zero-padded neighbour slots (fewer than 64 atoms, or a table of fewer than 64 columns) is flagged by the
+// unpack launch like a range overflow and repeated on the exact kernels by PESTO_PRECISION_AUTO: padded slots (wrap-around geometry against
+// the sink's zero state, src/model_operations.py:8,17) are where the forward is ill-conditioned for ANY fp32 evaluation - on the pinned
+// inputs of tests/golden/fuzz_pins.npz all of the deviation sits in the padded members (the 2-atom member of a collated batch: 1.3e-4
+// on its one residue, every other residue <= 2e-5; the reference's own fp32 run is 1.15e-4 off there). Real structures have no such slots.
+struct SatCtx { int* flags = nullptr; int* sflags = nullptr; const int* seg_of_atom = nullptr; int frame_n = 0; float state_limit = __builtin_huge_valf();
+                int pad_trigger = 0; };
 constexpr int SATCTX_OFFSET_INTS = 3;      // flags buffer: [0] unused, [1] the flags word, [2] collate's copy, [3] pad, [4..] SatCtx (16-byte aligned)
 void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero = nullptr,
                   ClearArgs clr = ClearArgs(), SatCtx sc = SatCtx());      // sc.flags non-null: the context is stored behind that word

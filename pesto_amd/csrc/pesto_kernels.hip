@@ -101,6 +101,15 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ W, MlpW
     }
 }
 
+// conditioning trigger of PESTO_PRECISION_AUTO for zero-padded neighbour slots (SatCtx::pad_trigger): called by ONE lane of a wave that met
+// a padded slot; row = state row (1-based) of an atom of the structure. The context was stored behind the flags word by the embed launch.
+__device__ __forceinline__ void pad_flag_at(int* __restrict__ err_flag, int64_t row) {
+    const SatCtx sc = *reinterpret_cast<const SatCtx*>(err_flag + SATCTX_OFFSET_INTS);
+    if (!sc.pad_trigger || !sc.sflags || row < 1) return;
+    atomicOr(err_flag, 4);
+    atomicOr(sc.sflags + (sc.seg_of_atom ? sc.seg_of_atom[row - 1] : sc.frame_n ? (int)((row - 1) / sc.frame_n) : 0), 4);
+}
+
 // ------------------------------------------------------------------------------------------------ geometry
 // pass 1: R = X[ids-1] - X[i] (ids-1 = -1 wraps to the last atom), D = |R|, block max -> atomic max of the
 // float bit pattern (D >= 0). Output rows are shifted by the sink row.   src/model_operations.py:8-10
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
         const int sg = seg_of_atom[i];
         long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
         if (id < 0 || id > Nf) { atomicOr(err_flag, 1); id = 0; }
+        if (__ballot(id == 0) != 0 && (threadIdx.x & 63) == 0) pad_flag_at(err_flag, (int64_t)i + 1);      // (a wave = the 64 slots of one atom)
         const long long j = id > 0 ? id - 1 : (long long)seg_end[sg] - 1;
         const float* xj = Xf + j * xs_atom;
         const float* xi = Xf + (int64_t)i * xs_atom;
@@ -146,11 +156,13 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
         return;
     }
     // 4 slots per thread (grid-stride by the grid size) keeps the number of blocks, hence atomics, at a quarter
+    bool padded = false;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)Nf * KMAX; e += (int64_t)gridDim.x * 256) {
         const int i = (int)(e >> 6), c = (int)(e & 63);
         if (sb.roa && c == 0) seg_bound_atom(i, sb.R, sb.roa, sb.lo_enc, sb.hi, sb.err_flag);
         long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
         if (id < 0 || id > Nf) { atomicOr(err_flag, 1); id = 0; }
+        padded = padded || id == 0;
         long long j = id - 1;
         if (j < 0) j += Nf;
         const float* xj = Xf + j * xs_atom;
@@ -163,6 +175,7 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
     }
     // wave max -> block max -> ONE atomic per block (a single word saturates at ~90 atomics/us: one per wave
     // cost 277 us at 24k atoms)
+    if (__ballot(padded) != 0 && (threadIdx.x & 63) == 0) pad_flag_at(err_flag, a0 + 1);      // (a block = atoms of ONE frame / of the one collated call)
     __shared__ float wmax[4];
     for (int off = 32; off > 0; off >>= 1) d = fmaxf(d, __shfl_xor(d, off));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = d;

@@ -1655,6 +1655,20 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         // fine-item nn = 32 instantiation (one-structure launches): at the 168-register limit the two live float4 spill there (20 B per
         // lane, +0.7 us per launch, measured in both pairs of profiles/r04_epilogue_ab.txt). Writer and reader share this switch.
         constexpr bool W3SPLIT = !(FIN && NN == 32 && TI == 2);
+        // SP (round 5): ONE pass per tile for the centres of several tiles (nn = 32 / 64). The softmax of the split path is unnormalised
+        // since this round (exp2 without the row maximum), so a tile's attention weights exp2(t) are known as soon as its key networks have
+        // run: the value network follows in the same tile and reuses its p_j . r_hat operand (what one-tile items do, ONEP) - no second
+        // gather of the six p_j pieces, projection, split and lane move per tile, no logits round trip through LDS - and the weighted
+        // sums are taken with the unnormalised weights; the row sums are accumulated per lane and 1 / sum is applied once per centre in
+        // the epilogue. Gives up the gather prefetch across the tiles of an item. Every instantiation of an nn switches together (the
+        // normalisation order changes the rounding: a structure must give the same bits alone and in a batch).
+        // Same box (profiles/r05_sp_ab.txt): nn = 64 265.4 -> 253.7 us per launch (-4.4 %), nn = 32 150.0 -> 144.1 (-3.9 %), 1,755 -> 1,818
+        // structures/s (+3.6 %). -DPESTO_NO_SP builds the two-pass form of rounds 1 - 4.
+#ifndef PESTO_NO_SP
+        constexpr bool SP = F16 && HY && FIN && !PF && !M32 && TPC >= 2;
+#else
+        constexpr bool SP = false;
+#endif
         L1RawAC rac2;
         f16x8 pr_h, pr_l;
         (void)rac2; (void)pr_h; (void)pr_l;
@@ -1674,7 +1688,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         (void)v_first; (void)pv_first;
         {
             // layers 2/3 of the key networks for one tile, raw logits parked in the (not yet used) attention-weight table
-            auto keys_of_tile = [&](int t, const f32x4* h1) {
+            auto keys_of_tile = [&](int t, const f32x4* h1, float* lg_regs = nullptr) {      // lg_regs: the two logits of this lane stay in registers (SP)
                 f32x4 acc2[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc2[m] = ld4(sm.w + EL_B2 + 16 * m + 4 * g);
@@ -1745,11 +1759,228 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 const int aMine = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
                 const float* Qv = rec_cen + (size_t)ABL_CEN(min(c0 + aMine, N1 - 1)) * REC_CEN + 512 + (g == 0 ? 0 : 6);
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    ws.wts[h * 4 + g][16 * t + e] = F16 ? Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]      // t = log2(e) logit / sdk: Q' carries the scale
-                                                        : (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) * inv_sdk;
+                for (int h = 0; h < 2; ++h) {
+                    const float lgt = F16 ? Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]      // t = log2(e) logit / sdk: Q' carries the scale
+                                          : (Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]) * inv_sdk;
+                    if (lg_regs) lg_regs[h] = lgt; else ws.wts[h * 4 + g][16 * t + e] = lgt;
+                }
             };
-            if (PF) {
+            if constexpr (SP) {
+                float zq[2][2], zp1[2][3][2];
+                f32x4 z3a[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+                float srow[2] = {0.f, 0.f};                          // per lane: sum over the centre's tiles of exp2(t) of (part g, edge e)
+                float pi3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) { zq[h][k] = 0.f; zp1[h][0][k] = zp1[h][1][k] = zp1[h][2][k] = 0.f; }
+                const int esub = lane >> 5, quad = (lane & 31) < 24 ? (lane & 31) : (lane & 31) - 24;      // (EPI2 lane layout of the p_j gathers)
+#pragma unroll 1
+                for (int t = 0; t < TI; ++t) {
+                    const TileCtx tcc = tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
+                    if (t % TPC == 0) {
+                        const int ic = ABL_CEN(min(c0 + (16 * t) / NN, N1 - 1));
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) pi3[c] = p_state[(size_t)ic * 96 + c * 32 + 16 * (g & 1) + e];
+                    }
+                    const L1Raw raw = l1_issue<NN>(0, t, lane, tcc, ws, p_state);
+                    __builtin_amdgcn_sched_barrier(0);
+                    L1Head hd = l1_head<NN>(raw, t, lane, tcc, ws);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const L1RawAC rac = l1_issue_ac<NN>(4, lane, tcc);      // the second half's A_j chunks / centre columns: in flight under the key networks
+                    const f16x8 keep_h = hd.fh, keep_l = hd.fl;
+                    __builtin_amdgcn_sched_barrier(0);
+                    float lgt[2];
+                    {
+                        f32x4 h1[4];
+                        __builtin_amdgcn_s_setprio(1);
+                        l1_tail(hd, 0, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
+                        keys_of_tile(t, h1, lgt);
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                    // unnormalised attention weights of this tile (same table layout as the two-pass code), row sums per lane
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float ex = __builtin_amdgcn_exp2f(lgt[h]);
+                        srow[h] += ex;
+                        ws.wts[h * 4 + g][16 * t + ((W3SPLIT && g == 3) ? ((e & 1) << 3) + (e >> 1) : e)] = ex;
+                    }
+                    f32x4 pv[4];
+                    {   // neighbours' p_j of the first half of the tile's edges (part-3 sums)
+                        int nbj[4];
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 2 * i2 + (esub & 1)]);
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- value network of the same tile: the operand (keep_h, keep_l) is the first pass's
+                    f32x4 h1v[4];
+                    {
+                        L1Head hv = l1_head_ac<NN>(rac, keep_h, keep_l, lane, tcc);
+                        __builtin_amdgcn_s_setprio(1);
+                        l1_tail(hv, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1v, sat);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (W3SPLIT) {
+                        const f32x4 w0 = ld4(&ws.wts[3][16 * t + 8 * (esub & 1)]), w1 = ld4(&ws.wts[7][16 * t + 8 * (esub & 1)]);
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) { z3a[0] += w0[i2] * pv[i2]; z3a[1] += w1[i2] * pv[i2]; }
+                    } else {
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) {
+                            const int ee = 2 * i2 + (esub & 1);
+                            const float w0 = ws.wts[3][16 * t + ee], w1 = ws.wts[7][16 * t + ee];
+                            z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 acc2[4];
+#pragma unroll
+                    for (int ml = 0; ml < 4; ++ml) acc2[ml] = ld4(sm.w + EL_B2 + 64 + 16 * ml + 4 * g);
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) {
+                        f16x8 xh, xl;
+                        split8(h1v[2 * kgp], h1v[2 * kgp + 1], xh, xl);
+#pragma unroll
+                        for (int m0 = 0; m0 < 4; m0 += 2) {
+                            f16x8 wh[2], wl[2];
+#pragma unroll
+                            for (int ml = 0; ml < 2; ++ml) {
+                                const float* fr = w2f + 8 * 256 + (size_t)(((m0 + ml) * 2 + kgp) * 2) * 256 + lane * 4;
+                                wh[ml] = ld8h(fr); wl[ml] = PESTO_WL(fr);
+                            }
+#pragma unroll
+                            for (int ml = 0; ml < 2; ++ml) acc2[m0 + ml] = MFMA16(wh[ml], xh, acc2[m0 + ml]);
+#pragma unroll
+                            for (int ml = 0; ml < 2; ++ml) acc2[m0 + ml] = MFMA16(wh[ml], xl, acc2[m0 + ml]);
+#pragma unroll
+                            for (int ml = 0; ml < 2; ++ml) acc2[m0 + ml] = MFMA16(wl[ml], xh, acc2[m0 + ml]);
+                        }
+                    }
+                    sat_probe(sat, acc2[0][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    {   // second half of the tile's edges: these loads land during the MFMA phase
+                        int nbj[4];
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)]);
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 h2[4];
+#pragma unroll
+                    for (int ml = 0; ml < 4; ++ml) h2[ml] = elu4s(acc2[ml]);
+                    f32x4 v[4];
+#pragma unroll
+                    for (int fo = 0; fo < 4; ++fo) v[fo] = ld4(&sm.b3v4[4 * (16 * fo + e)]);
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) {
+                        f16x8 ah, al;
+                        split8(h2[2 * kgp], h2[2 * kgp + 1], ah, al);
+#pragma unroll
+                        for (int f0 = 0; f0 < 4; f0 += 2) {
+                            f16x8 bh[2], bl[2];
+#pragma unroll
+                            for (int fo = 0; fo < 2; ++fo) {
+                                const float* fr = w3v + (size_t)(((f0 + fo) * 2 + kgp) * 2) * 256 + lane * 4;
+                                bh[fo] = ld8h(fr); bl[fo] = PESTO_WL(fr);
+                            }
+#pragma unroll
+                            for (int fo = 0; fo < 2; ++fo) v[f0 + fo] = MFMA16(ah, bh[fo], v[f0 + fo]);
+#pragma unroll
+                            for (int fo = 0; fo < 2; ++fo) v[f0 + fo] = MFMA16(al, bh[fo], v[f0 + fo]);
+#pragma unroll
+                            for (int fo = 0; fo < 2; ++fo) v[f0 + fo] = MFMA16(ah, bl[fo], v[f0 + fo]);
+                        }
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    if constexpr (W3SPLIT) {
+                        const f32x4 w0 = ld4(&ws.wts[3][16 * t + 8 * (esub & 1) + 4]), w1 = ld4(&ws.wts[7][16 * t + 8 * (esub & 1) + 4]);
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) { z3a[0] += w0[i2] * pv[i2]; z3a[1] += w1[i2] * pv[i2]; }
+                    } else {
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) {
+                            const int ee = 8 + 2 * i2 + (esub & 1);
+                            const float w0 = ws.wts[3][16 * t + ee], w1 = ws.wts[7][16 * t + ee];
+                            z3a[0] += w0 * pv[i2]; z3a[1] += w1 * pv[i2];
+                        }
+                    }
+                    // attention-weighted sums over this lane's four edges, unnormalised weights (:143-144, first block of Vp :132)
+                    const int r0 = 16 * t + 4 * g;
+                    const f32x4 gx = ld4(&ws.geo[0][r0]), gy = ld4(&ws.geo[1][r0]), gz = ld4(&ws.geo[2][r0]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 wq = ld4(&ws.wts[h * 4 + 0][r0]), w1 = ld4(&ws.wts[h * 4 + 1][r0]);
+                        const f32x4 wx4 = w1 * gx, wy4 = w1 * gy, wz4 = w1 * gz;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            zq[h][0] += wq[r] * v[0][r];
+                            zq[h][1] += wq[r] * v[1][r];
+                            const float wx = wx4[r], wy = wy4[r], wz = wz4[r];
+                            zp1[h][0][0] += wx * v[2][r]; zp1[h][0][1] += wx * v[3][r];
+                            zp1[h][1][0] += wy * v[2][r]; zp1[h][1][1] += wy * v[3][r];
+                            zp1[h][2][0] += wz * v[2][r]; zp1[h][2][1] += wz * v[3][r];
+                        }
+                    }
+                    if ((t + 1) % TPC != 0) continue;      // the centre continues in the next tile
+                    // ---- centre complete: the softmax denominators, then the epilogue (reduce-scatter on permlane swaps) with 1 / sum applied
+                    __builtin_amdgcn_sched_barrier(0);
+                    float rq[2], rv[2], wsm[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float s_row = row_reduce<true, false>(srow[h]);                    // this part's sum over the centre's edges
+                        const float tot_v = xrow<false>(xhalf<false>(g == 0 ? 0.0f : s_row));    // parts 1..3 together, every lane
+                        const float tot_q = lane_bcast(s_row, 0), s2 = lane_bcast(s_row, 32);    // part 0 / part 2 (wave-uniform)
+                        rq[h] = __builtin_amdgcn_rcpf(tot_q);
+                        rv[h] = __builtin_amdgcn_rcpf(tot_v);
+                        sat_probe(sat, tot_q); sat_probe(sat, rq[h] * 0x1p27f);                  // range guard of the unsubtracted softmax
+                        sat_probe(sat, tot_v); sat_probe(sat, rv[h] * 0x1p27f);
+                        wsm[h] = s2 * rv[h];                                                     // the centre's part-2 share (multiplies p_i)
+                        srow[h] = 0.f;
+                    }
+                    if (sat != sat) {
+                        const int rowc = c0 + (16 * t) / NN;
+                        if (rowc < N1) sat_flush_at(sat, flags, rowc);
+                    }
+                    sat = 0.0f;
+                    float Qt[2], Pt[2][3];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        Qt[h] = swap_add_rows(zq[h][0], zq[h][1]);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) Pt[h][c] = swap_add_rows(zp1[h][c][0], zp1[h][c][1]);
+                    }
+                    Qt[0] = swap_add_halves(Qt[0], Qt[1]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Pt[0][c] = swap_add_halves(Pt[0][c], Pt[1][c]);
+                    {
+                        f32x4 za;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) za[j] = swap_add_halves(z3a[0][j], z3a[1][j]);
+                        if ((lane & 31) < 24) st4(&ws.z3buf[0][lane >> 5][4 * (lane & 31)], za);
+                        z3a[0] = f32x4{0, 0, 0, 0}; z3a[1] = f32x4{0, 0, 0, 0};
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    {
+                        const int s_l = 16 * (g & 1) + e, hh = g >> 1;
+                        const int slot0 = SUBS > 1 ? sub : (16 * t) / NN;
+                        float* zb = zrow[slot0];
+                        const float rqh = hh ? rq[1] : rq[0], rvh = hh ? rv[1] : rv[0], wsh = hh ? wsm[1] : wsm[0];
+                        zb[hh * 32 + s_l] = Qt[0] * rqh;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) zb[64 + c * 64 + hh * 32 + s_l] = (Pt[0][c] + ws.z3buf[0][hh][c * 32 + s_l]) * rvh + wsh * pi3[c];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) { zq[h][k] = 0.f; zp1[h][0][k] = zp1[h][1][k] = zp1[h][2][k] = 0.f; }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else if (PF) {
                 // tile-batched: the four first-layer blocks of a tile are computed together (VALU phase, independent
                 // chains), then the layer-2/3 MFMA chains run dense; the NEXT tile's gathers are issued in between
                 TileCtx tc[2];
@@ -1869,6 +2100,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 }
             }
         }
+        if constexpr (!SP) {
         float lg[4][2];
 #pragma unroll
         for (int t = 0; t < TI; ++t) { lg[t][0] = ws.wts[g][16 * t + e]; lg[t][1] = ws.wts[4 + g][16 * t + e]; }
@@ -2362,6 +2594,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             __builtin_amdgcn_wave_barrier();
             PHASE_MARK(6);
         }
+        }      // !SP
         if (F16 && !FIN) sat = 0.0f;
         }   // !M32
       }   // work item

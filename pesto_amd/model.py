@@ -44,6 +44,7 @@ class Model:
         self._debug = (0, 0)        # pesto_debug_select(layer_kernels, knn_brute_force): test hook
         self._edge_mode = 0         # pesto_debug_edge_mode: test hook
         self._state_limit = None    # pesto_set_auto_state_limit (None: library default)
+        self._pad_trigger = None    # pesto_set_auto_pad_trigger (None: library default = on)
         self._last_device_call = None           # async_auto: tensors of the last device call (kept alive for its deferred check)
         self._blob = None
         self._handle = None
@@ -106,6 +107,14 @@ class Model:
         self._state_limit = None if limit is None else float(limit)
         if self._handle is not None and self._state_limit is not None:
             _lib.check(_lib.load().pesto_set_auto_state_limit(self._handle, self._state_limit))
+        return self
+
+    def set_auto_pad_trigger(self, enabled=True):
+        """pesto_set_auto_pad_trigger: precision "auto" repeats structures with zero-padded neighbour slots (fewer than 64 atoms / columns) on
+        the exact fp32 kernels - the inputs on which the forward is ill-conditioned for any fp32 evaluation. On by default."""
+        self._pad_trigger = bool(enabled)
+        if self._handle is not None:
+            _lib.check(_lib.load().pesto_set_auto_pad_trigger(self._handle, 1 if self._pad_trigger else 0))
         return self
 
     def status(self):
@@ -205,6 +214,8 @@ class Model:
                 _lib.check(lib.pesto_debug_edge_mode(h, self._edge_mode))
             if self.async_auto:
                 _lib.check(lib.pesto_set_async_auto(h, 1))
+            if getattr(self, "_pad_trigger", None) is not None:
+                _lib.check(lib.pesto_set_auto_pad_trigger(h, 1 if self._pad_trigger else 0))
             if getattr(self, "_state_limit", None) is not None:
                 _lib.check(lib.pesto_set_auto_state_limit(h, self._state_limit))
         return self._handle

@@ -37,7 +37,10 @@ def _model(tag, impl=None):
     precision, twin = _IMPL_ARGS[impl or _IMPL["name"]]
     m = Model(CONFIGS[tag], precision=precision).debug_select(twin)
     m.load_state_dict(weights(tag))
-    return m.eval()
+    # these tests pin the KERNELS (bit identities between launch shapes, staged and fused chains, batch and single calls), several of them on
+    # structures of fewer than 64 atoms: "auto"'s pad trigger (pesto_set_auto_pad_trigger: such structures are repeated on the exact
+    # kernels) is a policy on top and is tested in tests/test_fuzz_pins.py - off here
+    return m.set_auto_pad_trigger(False).eval()
 
 
 def _oracle(tag):

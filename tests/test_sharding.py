@@ -239,7 +239,9 @@ def _hip_worker(rank, world, port, out_dir, backend):
     try:
         m = _hip_model().to(f"cuda:{gpu}")
         res = sharding.forward_sharded(m, _hip_structures(), n_out=5, max_atoms=2000)
-        assert m.status()["n_fp32_rerun"] == 0      # grouping-independence is bitwise only while no launch is repeated in fp32
+        # (default policy: the member of 40 atoms is repeated on the exact kernels by the pad trigger - on whichever rank owns it, and in
+        # the one-call-per-structure run it is compared with: per-structure guard words keep the grouping-independence bitwise)
+        assert m.status()["n_fp32_rerun"] <= 1
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{str(i): z for i, z in enumerate(res)})
     finally:
         dist.destroy_process_group()
