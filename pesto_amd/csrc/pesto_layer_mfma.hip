@@ -1664,8 +1664,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         // normalisation order changes the rounding: a structure must give the same bits alone and in a batch).
         // Same box (profiles/r05_sp_ab.txt): nn = 64 265.4 -> 253.7 us per launch (-4.4 %), nn = 32 150.0 -> 144.1 (-3.9 %), 1,755 -> 1,818
         // structures/s (+3.6 %). -DPESTO_NO_SP builds the two-pass form of rounds 1 - 4.
+#ifndef PESTO_SP_MIN_NN
+#define PESTO_SP_MIN_NN 32
+#endif
+        constexpr int SP_MIN_NN = PESTO_SP_MIN_NN;
 #ifndef PESTO_NO_SP
-        constexpr bool SP = F16 && HY && FIN && !PF && !M32 && TPC >= 2;
+        constexpr bool SP = F16 && HY && FIN && !PF && !M32 && NN >= SP_MIN_NN;
 #else
         constexpr bool SP = false;
 #endif
