@@ -120,7 +120,9 @@ int pesto_set_auto_state_limit(pesto_model* m, float limit);
  * to the last atom, src/model_operations.py:8) - is repeated on the exact fp32 kernels. Padded slots are where the forward is
  * ill-conditioned for any fp32 evaluation (the reference's own fp32 and fp64 runs differ by 1.15e-4 on the pinned 2-atom member of
  * tests/golden/fuzz_pins.npz; the split kernels by 0.8 - 1.4e-4 depending on summation order, the exact kernels by 2e-5); real structures
- * have none, so the repeat costs nothing where throughput matters. enabled == 0 switches it off. F16_SPLIT / FP32 ignore it. */
+ * have none, so the repeat costs nothing where throughput matters. The repeat of AUTO runs the exact kernels over the WHOLE launch of a
+ * flagged structure (it writes only that structure's logits): bulk callers give such structures launches of their own
+ * (pesto_amd.sharding.forward_local and pesto_amd.apply.apply_model do). enabled == 0 switches it off. F16_SPLIT / FP32 ignore it. */
 int pesto_set_auto_pad_trigger(pesto_model* m, int32_t enabled);
 
 /* replaces: Model.forward(X, ids_topk, q0, M)  (model/model.py:32-52).

@@ -143,6 +143,8 @@ def _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_erro
             hand_out(done)
 
         group, atoms = [], 0
+        small, small_atoms = [], 0      # structures of fewer than 64 atoms (zero-padded neighbour slots): launches of their own - precision "auto"
+                                        # repeats them on the exact kernels, and that repeat covers the whole launch (sharding.forward_local)
         for path, fut in loads:
             try:
                 s, X, q, roa, R = fut.result()
@@ -150,12 +152,20 @@ def _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_erro
                 if on_error:
                     on_error(f"error with {path}: {e}")
                 continue
+            if len(s) < 64:
+                if small and small_atoms + len(s) > max_atoms:
+                    flush(small)
+                    small, small_atoms = [], 0
+                small.append((path, s, X, q, roa, R))
+                small_atoms += len(s)
+                continue
             if group and atoms + len(s) > max_atoms:
                 flush(group)
                 group, atoms = [], 0
             group.append((path, s, X, q, roa, R))
             atoms += len(s)
         flush(group)
+        flush(small)
         hand_out(fetch())
         for w in writes:
             w.result()

@@ -3230,7 +3230,7 @@ static double rounds_paid(int n_work, int waves, int subs) {
 }
 static bool node_wave_mode(int nn, int n_work) {
     const int subs = nn == 64 ? 2 : 1;                                     // items per wave and iteration (two staged centres per wave)
-    const double cost = nn == 8 ? 0.87 : nn == 16 ? 0.94 : nn == 32 ? 0.985 : 1.023;      // (nn = 8 / 16 re-measured in round 5: 56.1 vs 66.9, 86.1 vs 91.6 us)      // (nn = 32 re-measured in round 3: 158.5 vs 160.8-165 us at 8 x 3,000 atoms)
+    const double cost = nn == 8 ? 0.87 : nn == 16 ? 0.94 : nn == 32 ? 0.95 : 1.023;      // (re-measured in round 5: nn = 8 56.1 vs 66.9, nn = 16 86.1 vs 91.6, nn = 32 with one pass per tile 144.4 vs 152.2 us)
     return rounds_paid(n_work, 8, subs) * cost < rounds_paid(n_work, 12, subs);
 }
 // M32: the 32-edge-tile kernel (v_mfma_f32_32x32x16_f16, eight-wave rendezvous workgroups); its gathers use 32-bit buffer offsets

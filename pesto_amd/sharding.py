@@ -109,7 +109,15 @@ def forward_local(forward_fn, structures, indices, max_atoms=24576, raise_if_all
             r0 += r
 
     last_error = None
-    groups = batches(indices, sizes, max_atoms)
+    # structures with zero-padded neighbour slots (fewer than 64 atoms / columns) get launches of their own: precision "auto" repeats such
+    # structures on the exact fp32 kernels (pesto_set_auto_pad_trigger), and the repeat runs the exact kernels over the WHOLE launch of a
+    # flagged structure (writing only its logits) - one peptide must not make 24,000 atoms of batch mates pay for it. Results do not
+    # depend on the grouping (PESTO_BATCH_INDEPENDENT), so this is a cost decision only.
+    def _padded(i):
+        ids = structures[i][1]
+        return sizes[i] < 64 or (np.ndim(ids) == 2 and np.shape(ids)[1] < 64)
+    small = [i for i in indices if _padded(i)]
+    groups = batches([i for i in indices if not _padded(i)], sizes, max_atoms) + (batches(small, sizes, max_atoms) if small else [])
     # a pesto_amd.Model: two launches in flight (submit t + 1 while t computes: host packing and the H2D copy overlap the kernels)
     pipelined = hasattr(forward_fn, "forward_batch_submit")
     pending = None      # (group, ticket) of the launch in flight

@@ -126,6 +126,23 @@ def test_weights_are_broadcast_from_rank0_and_checked(tmp_path):
         Model(CONFIGS["i_v4_0"]).load_blob(want[:-1])
 
 
+def test_padded_structures_get_launches_of_their_own():
+    """precision "auto" repeats a structure with zero-padded neighbour slots on the exact kernels, and that repeat covers its whole launch:
+    forward_local keeps such structures (fewer than 64 atoms, or a table of fewer than 64 columns) out of the launches of the others."""
+    from pesto_amd.topology import synthetic_structure
+    structures = [synthetic_structure(n, 7 + i) for i, n in enumerate((120, 30, 200, 64, 17, 90))]
+    structures.append((structures[0][0], structures[0][1][:, :8], structures[0][2], structures[0][3]))      # 120 atoms, 8 columns
+    seen = []
+
+    class Recorder:
+        def forward_batch(self, structs, independent=True):
+            seen.append([s[0].shape[0] if np.shape(s[1])[1] == 64 or s[0].shape[0] < 64 else -s[0].shape[0] for s in structs])
+            return [np.zeros((np.asarray(s[3]).shape[1], 5), np.float32) for s in structs]
+    res = sharding.forward_local(Recorder(), structures, list(range(len(structures))), max_atoms=10000)
+    assert len(res) == len(structures)
+    assert sorted(map(sorted, seen)) == sorted([sorted([120, 200, 64, 90]), sorted([30, 17, -120])])
+
+
 def test_failed_structure_is_skipped_not_fatal():
     structures = _structures()[:3]
     calls = {"n": 0}
