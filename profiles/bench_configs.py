@@ -76,7 +76,7 @@ a3 = dev_args(X, ids, q, roa)
 timed(lambda: m30.forward_segments(a3[0], a3[1], a3[2], a3[3], R3), 8, "3: i_v3_0 (16 layers, N0=123), 8 x N=3000")
 
 from bench import config4_structures  # noqa: E402
-chains, sizes, _ = config4_structures(53, m41)        # the 53 REAL pdbs_test chains (tests/golden/cfg4_all53.npz)
+chains, sizes, _ = config4_structures(53, m41, "dense")        # the 53 REAL pdbs_test chains (tests/golden/cfg4_all53.npz)
 groups = batches(list(range(53)), sizes, 24600)
 prepared = []
 for grp in groups:
