@@ -36,7 +36,12 @@ void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq,
 // calls - per-structure wrap-around target and max(D); dmax_bits then holds one zeroed word per structure
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
                    int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag, const int* seg_of_atom = nullptr,
-                   const int* seg_end = nullptr, SegBoundsArgs sb = SegBoundsArgs());
+                   const int* seg_end = nullptr, SegBoundsArgs sb = SegBoundsArgs(), bool skip_pass2 = false);
+// pass 2 of the geometry (D += max(D) (D < 1e-2), R /= D, sink row; src/model_operations.py:12-20) as extra workgroups of the node launch
+// that writes the first layer's records: small launches (one structure) then pay one dependent launch less (round 5). n = N atoms in total.
+struct Unpack2Args { int n = 0; int Nf = 0; int* ids_s = nullptr; float4* geo = nullptr; const unsigned* dmax_bits = nullptr; const int* seg_of_atom = nullptr; };
+// workgroups of 512 threads the merged form adds for n atoms (0 = do not merge: the node launch's own workgroups + these must fit one wave of 256 CUs)
+int unpack2_merge_blocks(int n_atoms, int N1);
 void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int* roa_f, int* err_flag);
 void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                      const float* q_in, const float* p_in, float* q_out, float* p_out);
@@ -44,7 +49,7 @@ void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, c
 // flags: the flags word (the SatCtx of the launch lies behind it); the f16-split kernels set bit 2 (value 4) of it and of the
 // structure's word when an activation left the f16 range (sat_probe)
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
-                 const float* Z, float* rec_nb, float* rec_cen, int variant, int* flags);
+                 const float* Z, float* rec_nb, float* rec_cen, int variant, int* flags, Unpack2Args u2 = Unpack2Args());
 // Z of a fused launch (q_out != nullptr): the operand stash of the edge kernel - at least EDGE_STASH_BYTES, whatever N1 is
 constexpr size_t EDGE_STASH_BYTES = (size_t)256 * 12 * 4 * 2048;
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,

@@ -620,7 +620,7 @@ void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq,
 
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
                    int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag, const int* seg_of_atom, const int* seg_end,
-                   SegBoundsArgs sb) {
+                   SegBoundsArgs sb, bool skip_pass2) {
     const int64_t n1 = (int64_t)Nf * KMAX, nall = (int64_t)Nf * F * KMAX;
     const dim3 grid1((unsigned)((n1 + (seg_of_atom ? 255 : 1023)) / (seg_of_atom ? 256 : 1024)), (unsigned)F),
         grid2((unsigned)((nall + KMAX + 255) / 256));
@@ -630,7 +630,7 @@ void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t
     else
         hipLaunchKernelGGL(k_unpack1<int>, grid1, dim3(256), 0, st, Nf, k, X, xs_frame, xs_atom, (const int*)ids, ids_s, geo, dmax_bits,
                            err_flag, seg_of_atom, seg_end, sb);
-    hipLaunchKernelGGL(k_unpack2, grid2, dim3(256), 0, st, Nf * F, Nf, ids_s, geo, dmax_bits, seg_of_atom);
+    if (!skip_pass2) hipLaunchKernelGGL(k_unpack2, grid2, dim3(256), 0, st, Nf * F, Nf, ids_s, geo, dmax_bits, seg_of_atom);      // (else: inside the node launch, launch_node)
 }
 
 void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int* roa_f, int* err_flag) {

@@ -404,7 +404,21 @@ constexpr int NODE_LDS_FLOATS = NL_NQ + 3584;
 __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
                                                 int N1, float* __restrict__ q_state, float* __restrict__ p_state,
                                                 const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen,
-                                                int* __restrict__ flags) {
+                                                int* __restrict__ flags, Unpack2Args u2, int n_node_blocks) {
+    if ((int)blockIdx.x >= n_node_blocks) {
+        // extra workgroups of a small launch: pass 2 of the geometry (k_unpack2's statement, the same expressions: same bits) - it only
+        // depends on the launch in front (max(D)), like the records this launch writes only depend on the embedding
+        const int64_t n_slots = (int64_t)(u2.n + 1) * KMAX;
+        for (int64_t s_ = (int64_t)(blockIdx.x - n_node_blocks) * (NODE_WAVES * 64) + threadIdx.x; s_ < n_slots;
+             s_ += (int64_t)(gridDim.x - n_node_blocks) * (NODE_WAVES * 64)) {
+            if (s_ < KMAX) { u2.ids_s[s_] = 0; u2.geo[s_] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            const float dmax = __uint_as_float(u2.dmax_bits[u2.seg_of_atom ? u2.seg_of_atom[(s_ >> 6) - 1] : ((s_ >> 6) - 1) / u2.Nf]);
+            float4 gg = u2.geo[s_];
+            const float d = gg.w + dmax * (gg.w < 1e-2f ? 1.0f : 0.0f);
+            u2.geo[s_] = make_float4(gg.x / d, gg.y / d, gg.z / d, d);
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
     float sat = 0.0f;
     // wave-uniform by construction; readfirstlane makes it uniform for the compiler too (scalar branches around the MFMA blocks)
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
     }
     // XCD-aware partition of tile PAIRS (same atom ranges per XCD as the edge kernel's work items)
     const int n_tiles = (N1 + 15) >> 4, n_pairs = (n_tiles + 1) >> 1, chunk = (n_pairs + 7) >> 3;
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nbx = n_node_blocks >> 3;
     const int p_end = min(n_pairs, (xcd + 1) * chunk);
     bool first = true;
     for (int pair = xcd * chunk + jb; pair < p_end; pair += nbx) {
@@ -3153,8 +3167,18 @@ void debug_print_phase_cycles() {
 }
 
 // =============================================================================================== launchers
+static int node16_blocks(int N1) {
+    const int tiles = (N1 + 15) / 16, pair_chunk = ((tiles + 1) / 2 + 7) / 8;
+    return (pair_chunk < 32 ? pair_chunk : 32) * 8;
+}
+int unpack2_merge_blocks(int n_atoms, int N1) {
+    // four slots per thread; the merged launch must stay one wave of workgroups (k_node16 holds 118 KB of LDS: one workgroup per CU)
+    const int64_t slots = (int64_t)(n_atoms + 1) * KMAX;
+    const int extra = (int)((slots + NODE_WAVES * 64 * 4 - 1) / (NODE_WAVES * 64 * 4));
+    return node16_blocks(N1) + extra <= 256 ? extra : 0;
+}
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
-                 const float* Z, float* rec_nb, float* rec_cen, int variant, int* flags) {
+                 const float* Z, float* rec_nb, float* rec_cen, int variant, int* flags, Unpack2Args u2) {
     const int tiles = (N1 + 15) / 16, chunk = (tiles + 7) / 8;
     const LayerW dummy{};
     const LayerW& wf = finish ? *finish : dummy;
@@ -3165,9 +3189,9 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
         return;
     }
     // eight waves = two tiles per iteration; persistent workgroups, at most one per CU (32 per XCD)
-    const int pair_chunk = ((tiles + 1) / 2 + 7) / 8;
-    const dim3 grid((pair_chunk < 32 ? pair_chunk : 32) * 8), block(NODE_WAVES * 64);
-    hipLaunchKernelGGL(k_node16, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags);
+    const int n_node = node16_blocks(N1), extra = u2.geo ? unpack2_merge_blocks(u2.n, N1) : 0;
+    const dim3 grid(n_node + extra), block(NODE_WAVES * 64);
+    hipLaunchKernelGGL(k_node16, grid, block, 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z, rec_nb, rec_cen, flags, u2, n_node);
 }
 
 struct EdgeIO {     // per-launch pointers of the edge kernel
