@@ -20,25 +20,48 @@ def _load(path, n0):
     return s, X, q, roa, R
 
 
-def save_results(results, path):
-    """Bulk result file: what the reference's interfaceome driver keeps in an HDF5 store, ``hf[key] = p.cpu().numpy()`` per
-    structure (interfaceome/apply_model.py:53-79; h5py is not a dependency here). One .npz with the per-structure probability
-    tables stacked along the residue axis: ``keys`` [n] (str), ``offsets`` [n+1] (int64), ``p`` [sum R_i, n_out] (float32) -
-    structure i is p[offsets[i]:offsets[i+1]]. Written atomically (temporary file + rename)."""
-    keys = list(results)
-    tabs = [np.asarray(results[k], dtype=np.float32).reshape(len(results[k]), -1) for k in keys]
+def _is_h5(path):
+    return os.fspath(path).lower().endswith((".h5", ".hdf5", ".hdf"))
+
+
+def save_results(results, path, keys=None):
+    """Bulk result file of the reference's interfaceome driver, ``hf[key] = p.cpu().numpy()`` per structure
+    (interfaceome/apply_model.py:53-79). The extension picks the container:
+
+    * ``.h5`` / ``.hdf5``: an HDF5 file like the reference's - one float32 dataset [R, n_out] per key, groups along the ``/`` of a key
+      (h5store.H5Store: the HDF5 C library through ctypes, no h5py; raises h5store.H5Unavailable when the machine has no libhdf5 -
+      nothing is written in another format behind the caller's back). ``keys``: {result key -> dataset name}; default: the path
+      without its leading '/' (a file path is a valid HDF5 name; the reference's keys are its store's ``pdbid/assembly/chain`` names).
+    * anything else: one .npz with the per-structure tables stacked along the residue axis: ``keys`` [n] (str), ``offsets`` [n+1]
+      (int64), ``p`` [sum R_i, n_out] (float32) - structure i is p[offsets[i]:offsets[i+1]].
+    Both are written to a temporary file and renamed."""
+    path = os.fspath(path)
+    names = list(results)
+    tabs = [np.asarray(results[k], dtype=np.float32).reshape(len(results[k]), -1) for k in names]
+    if _is_h5(path):
+        from . import h5store
+        tmp = path + ".tmp"
+        with h5store.H5Store(tmp, "w") as hf:
+            for k, t in zip(names, tabs):
+                hf[(keys or {}).get(k, str(k).lstrip("/"))] = t
+        os.replace(tmp, path)
+        return path
     n_out = tabs[0].shape[1] if tabs else 0
-    offs = np.zeros(len(keys) + 1, dtype=np.int64)
+    offs = np.zeros(len(names) + 1, dtype=np.int64)
     offs[1:] = np.cumsum([t.shape[0] for t in tabs])
     p = np.concatenate(tabs, 0) if tabs else np.zeros((0, n_out), np.float32)
     tmp = path + ".tmp.npz"
-    np.savez_compressed(tmp, keys=np.array(keys, dtype=str), offsets=offs, p=p)
+    np.savez_compressed(tmp, keys=np.array(names, dtype=str), offsets=offs, p=p)
     os.replace(tmp, path)
     return path
 
 
 def load_results(path):
-    """{key: p [R, n_out]} from a file written by save_results."""
+    """{key: p [R, n_out]} from a file written by save_results (or, for .h5, by the reference's own loop)."""
+    if _is_h5(path):
+        from . import h5store
+        with h5store.H5Store(path) as hf:
+            return dict(hf.items())
     d = np.load(path)
     offs, p, keys = d["offsets"], d["p"], d["keys"]      # NpzFile decompresses an array on EVERY access: materialise each once
     return {str(k): p[offs[i]:offs[i + 1]] for i, k in enumerate(keys)}
@@ -48,7 +71,8 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
                 report_ties=True):
     """Returns {path: p} with p = sigmoid(z) as numpy [R, n_out] for every structure that could be processed.
     write=True also saves ``path[:-4] + suffix.format(i)`` for each output channel i (apply_model.ipynb:157-166).
-    results_path: also write all probability tables into one bulk result file (save_results), the reference's HDF5 store.
+    results_path: also write all probability tables into one bulk result file (save_results): ``*.h5`` = the reference's HDF5 store
+    (one dataset per structure), otherwise the .npz form.
     ``model``: a pesto_amd.Model on a GPU; max_atoms: atoms per launch (about 24k fills an MI355X).
     report_ties: log (logging "pesto_amd.apply", WARNING) the structures in which two neighbours at exactly the same float32 distance
     straddle a layer's neighbourhood cut-off - the rows on which the reference's torch.topk (src/data_encoding.py:98-99) may have chosen

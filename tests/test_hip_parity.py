@@ -602,6 +602,11 @@ def test_bulk_apply_model_pdb_in_pdb_out(tmp_path):
     assert set(res) == set(paths) and len(errors) == 1 and "broken.pdb" in errors[0]
     stored = load_results(str(tmp_path / "bulk.npz"))               # the bulk store (the reference's hf[key] = p)
     assert set(stored) == set(paths) and all(np.array_equal(stored[k], res[k]) for k in paths)
+    from pesto_amd import h5store
+    if h5store.available():                                         # ... and as the HDF5 file the reference's loop writes (no h5py: libhdf5 through ctypes)
+        from pesto_amd.apply import save_results
+        h5 = load_results(save_results(res, str(tmp_path / "bulk.h5")))
+        assert set(h5) == {k.lstrip("/") for k in paths} and all(np.array_equal(h5[k.lstrip("/")], res[k]) for k in paths)
     for p in paths:
         s = Structure.read_pdb(p).preprocess()
         X, q, roa, R = s.encode(30)
