@@ -368,6 +368,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preroll-ms", type=float, default=100.0,
+                    help="untimed run of the same step IN FRONT of the warm-up steps until this much time has passed: an idle MI355X takes "
+                         "~30 ms of work to reach its steady clocks (profiles/r05_clock_ramp.txt); the host-side set-up leaves it idle. 0 = none")
     ap.add_argument("--batch", type=int, default=8, help="structures per step per GPU")
     ap.add_argument("--atoms", type=int, default=3000)
     ap.add_argument("--config", default="i_v4_1")
@@ -379,6 +382,7 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="developer ablation builds only: do not check the timed output")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 and config-4 legs (profiling runs)")
     ap.add_argument("--config4-structures", type=int, default=64, help="structures PER RANK of the config-4 leg (the list has this many x world size)")
+    ap.add_argument("--config4-max-atoms", type=int, default=24576, help="atoms per collated launch of the config-4 legs (sharding.forward_sharded)")
     ap.add_argument("--strong-structures", type=int, default=512, help="size of the FIXED list of the config4_strong leg (N > 1 only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-gpu", action="store_true",
@@ -512,6 +516,15 @@ def run(args, stage):
         own = time.perf_counter() - t0_
         return [r_[0] for r_ in gather_rank_stats(dist, args.backend, dev, [own])]
 
+    # clock pre-roll (disclosed in the line as "preroll"): the set-up above is host work, the GPU is idle and at its idle clocks when the
+    # warm-up starts; the first ~30 ms of work after an idle period run 3 - 12 % slower than the steady state (profiles/r05_clock_ramp.txt)
+    preroll_steps = 0
+    if args.preroll_ms > 0:
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+            step()
+            torch.cuda.synchronize()
+            preroll_steps += 1
     elapsed, z = timed(args.warmup, args.steps)
     rank_times = timed_per_rank(args.steps) if world > 1 else None
     assert args.no_check or torch.isfinite(z).all()
@@ -671,31 +684,40 @@ def run(args, stage):
         del Md
 
     # ---- side measurement: batch-1 latency (ms per structure when structures arrive one at a time)
-    lat_ms = None
+    lat_ms = lat_detail = None
     if not args.no_latency and args.batch > 1:
         X1, ids1, q1, roa1, R1 = make_batch(args.atoms, 1, 1000 * rank + 1, n0, args.order)
         a = [torch.from_numpy(v).to(dev) for v in (X1, ids1, q1, roa1)]
-        for _ in range(3):
-            model.forward_segments(a[0], a[1], a[2], a[3], R1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            model.forward_segments(a[0], a[1], a[2], a[3], R1)
-        torch.cuda.synchronize()
-        lat_ms = (time.perf_counter() - t1) / 10 * 1e3
+        def calls(n):
+            t1 = time.perf_counter()
+            for _ in range(n):
+                model.forward_segments(a[0], a[1], a[2], a[3], R1)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n * 1e3
+        calls(3)
+        # a burst on an idle GPU: its first ten calls (what rounds 1 - 4 reported as ms_per_structure_batch1: 3 warm-up calls, 10 timed)
+        time.sleep(0.1)
+        lat_cold = calls(10)
+        # steady state of back-to-back calls: the clocks have ramped (about 30 calls, profiles/r05_clock_ramp.txt)
+        calls(30)
+        lat_ms = calls(50)
+        lat_detail = {"steady_state_ms": lat_ms, "calls": 50, "warmup_calls": 43,
+                      "first_10_calls_after_100ms_idle_ms": lat_cold,
+                      "note": "one model.forward_segments call per structure on device tensors, precision as the line; the GPU drops to its idle "
+                              "clocks within tens of ms without work and needs ~30 calls to ramp back (profiles/r05_clock_ramp.txt)"}
 
     # ---- BASELINE config 4 as a strong-scaling leg (every world size runs the same list)
     stage[0] = "config-4 legs (sharding.forward_sharded)"
     cfg4 = cfg4_dense = cfg4_strong = None
     if (not args.no_extras or args.mode == "strong") and args.config == "i_v4_1":
-        cfg4 = config4_leg(model, dist, args.backend, dev, args.config4_structures * world, max(3, min(args.steps, 5)), 24576)
+        cfg4 = config4_leg(model, dist, args.backend, dev, args.config4_structures * world, max(3, min(args.steps, 5)), args.config4_max_atoms)
         # the same list in the reference loader's OWN per-structure forms (dense one-hot q, bool M, int64 ids): every reduction inside the
         # timed region (ADVICE r4 / VERDICT r4 item 6: the compact leg above pre-reduces outside it)
-        cfg4_dense = config4_leg(model, dist, args.backend, dev, args.config4_structures * world, 3, 24576, forms="dense")
+        cfg4_dense = config4_leg(model, dist, args.backend, dev, args.config4_structures * world, 3, args.config4_max_atoms, forms="dense")
         if world > 1:
             # SURVEY 8e's acceptance is about a FIXED list (>= 7x on 8 GPUs, >= 64 structures): the same 512 structures at every world
             # size, with the world-1 time of that list taken on rank 0 inside this run
-            cfg4_strong = config4_leg(model, dist, args.backend, dev, args.strong_structures, 3, 24576, fixed_list=True)
+            cfg4_strong = config4_leg(model, dist, args.backend, dev, args.strong_structures, 3, args.config4_max_atoms, fixed_list=True)
         if rank == 0 and cfg4 is not None:
             cfg4["dense_forms"] = cfg4_dense
 
@@ -715,6 +737,10 @@ def run(args, stage):
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_structure": elapsed / n_struct * 1e3,
             "ms_per_structure_batch1": lat_ms,
+            "batch1": lat_detail,
+            "preroll": {"ms": args.preroll_ms, "steps": preroll_steps,
+                        "why": "untimed steps in front of the W warm-up steps: the host-side set-up leaves the GPU idle, and an idle MI355X needs "
+                               "~30 ms of work to reach its steady clocks"},
             "long_sample": long_sample,
             "reference_signature": ref_sig,
             "higher_is_better": True,
