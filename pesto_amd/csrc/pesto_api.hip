@@ -241,7 +241,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
     // conditioning trigger: only where a flagged structure is repeated (AUTO on the split kernels); f16_split never repeats, so it never flags
     const float state_limit = (!exact && m->precision == PESTO_PRECISION_AUTO && m->state_limit > 0.0f) ? m->state_limit : __builtin_huge_valf();
     const SatCtx sc{err_ptr(m), m->sflags.as<int>(), a.seg_of_atom, (!a.seg_of_atom && a.F > 1) ? (int)a.N : 0, state_limit,
-                    (!exact && m->precision == PESTO_PRECISION_AUTO && m->pad_trigger) ? 1 : 0};
+                    (!exact && m->precision == PESTO_PRECISION_AUTO && m->pad_trigger) ? 1 : 0, (exact && masked) ? 1 : 0};
     int* seg_lo = m->dmax.as<int>() + seg_off;
     int* seg_hi = seg_lo + RT;
     const bool bounds_in_embed = a.F == 1;             // found by the unpack launch (trajectory batches expand res_of_atom per frame behind it: separate launches)

@@ -26,8 +26,12 @@ struct ClearArgs { int* p0 = nullptr; int n0 = 0; int* p1 = nullptr; int n1 = 0;
 // the sink's zero state, src/model_operations.py:8,17) are where the forward is ill-conditioned for ANY fp32 evaluation - on the pinned
 // inputs of tests/golden/fuzz_pins.npz all of the deviation sits in the padded members (the 2-atom member of a collated batch: 1.3e-4
 // on its one residue, every other residue <= 2e-5; the reference's own fp32 run is 1.15e-4 off there). Real structures have no such slots.
+// only_flagged (round 5): the launch is AUTO's fp32 repeat - the exact layer kernels skip the work items (k_edge) / atom tiles (k_node) whose
+// atoms all belong to structures whose guard word is clear: their logits are not rewritten (launch_pool's only_flagged), and a structure's
+// neighbours are its own atoms and the sink row, so nothing a flagged structure reads is skipped. One small flagged structure in a
+// 24,000-atom launch then costs 32 nearly empty launch pairs instead of the whole launch at fp32 speed.
 struct SatCtx { int* flags = nullptr; int* sflags = nullptr; const int* seg_of_atom = nullptr; int frame_n = 0; float state_limit = __builtin_huge_valf();
-                int pad_trigger = 0; };
+                int pad_trigger = 0; int only_flagged = 0; };
 constexpr int SATCTX_OFFSET_INTS = 3;      // flags buffer: [0] unused, [1] the flags word, [2] collate's copy, [3] pad, [4..] SatCtx (16-byte aligned)
 void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq, int n0, const float* q0, float* q_state, float* p_zero = nullptr,
                   ClearArgs clr = ClearArgs(), SatCtx sc = SatCtx());      // sc.flags non-null: the context is stored behind that word

@@ -109,6 +109,18 @@ __device__ __forceinline__ void mag_flush_at(f32x4 a, f32x4 b, float limit, int*
         atomicOr(sc.sflags + (sc.seg_of_atom ? sc.seg_of_atom[row - 1] : sc.frame_n ? (row - 1) / sc.frame_n : 0), 4);
     }
 }
+// AUTO's fp32 repeat (SatCtx::only_flagged): does any of the n <= 64 atom rows i0 .. i0 + n - 1 belong to a structure whose guard word is set?
+// Wave-uniform (one ballot); row 0 is the sink, rows >= N1 do not exist.
+__device__ __forceinline__ bool only_flagged_of(const int* __restrict__ flags) {
+    return flags && reinterpret_cast<const SatCtx*>(flags + SATCTX_OFFSET_INTS)->only_flagged != 0;
+}
+__device__ __forceinline__ bool rows_flagged(const int* __restrict__ flags, int i0, int n, int N1, int lane) {
+    const SatCtx sc = *reinterpret_cast<const SatCtx*>(flags + SATCTX_OFFSET_INTS);
+    const int i = i0 + lane;
+    bool f = false;
+    if (lane < n && i > 0 && i < N1) f = (sc.sflags[sc.seg_of_atom ? sc.seg_of_atom[i - 1] : sc.frame_n ? (i - 1) / sc.frame_n : 0] & 4) != 0;
+    return __ballot(f) != 0;
+}
 __device__ __forceinline__ f16x8 ld8h(const float* p) { return *reinterpret_cast<const f16x8*>(p); }
 #ifdef PESTO_ABL_NOWL   // ablation: the low weight fragments are not read from LDS (results wrong): -1/3 of the LDS weight traffic
 #define PESTO_WL(fr) ld8h(fr) 
@@ -214,7 +226,8 @@ __device__ __forceinline__ void mfma_multi(const float* __restrict__ wf, int m0,
 // One wave = 16 atoms; lane (e = atom in tile, g).  Weight fragments stream from L2 (shared by all waves).
 __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, LayerW wf_, LayerW wp_, int do_finish, int do_prep,
                                               int N1, float* __restrict__ q_state, float* __restrict__ p_state,
-                                              const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen) {
+                                              const float* __restrict__ Z, float* __restrict__ rec_nb, float* __restrict__ rec_cen,
+                                              const int* __restrict__ flags) {
     const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
     // same XCD-aware atom partition as the edge kernel: XCD b % 8 owns a contiguous eighth of the 16-atom tiles,
     // so the records it writes are the ones its own L2 will be asked for by the edge kernel's centre reads
@@ -222,6 +235,9 @@ __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, Layer
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int tile = xcd * chunk + jb * 4 + (threadIdx.x >> 6);
     if (tile >= min(n_tiles, (xcd + 1) * chunk)) return;
+    // AUTO's fp32 repeat: tiles without an atom of a flagged structure are skipped (tile 0 never: it holds the sink row, whose records
+    // every padded neighbour slot gathers)
+    if (tile > 0 && only_flagged_of(flags) && !rows_flagged(flags, tile * 16, 16, N1, lane)) return;
     const int i_raw = tile * 16 + e;
     const bool valid = i_raw < N1;
     const int i = valid ? i_raw : N1 - 1;
@@ -1574,6 +1590,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     float sat = 0.0f, sat_b = 0.0f;
     constexpr bool SAT2 = F16 && FIN && !M32 && A == 2 && NN >= 16;
     int fin_iter = 0;       // finish phases done (FIN)
+    const bool only_fl = (!F16 && !FIN) ? only_flagged_of(flags) : false;      // (SatCtx::only_flagged: read once, uniform)
+    (void)only_fl;
     // the trip count is the same for every wave of a workgroup (FIN: workgroup barriers inside); a wave without a work item idles
     // An iteration hands every wave SUBS items. Full iterations: consecutive blocks of WPB items per wave-slot (neighbouring centres
     // share gathered lines in the L1). The LAST iteration of an XCD's share (fewer items left than slots - in a small launch the only
@@ -1598,7 +1616,11 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll 1
       for (int sub = 0; sub < SUBS; ++sub) {
       const int work = base + sub * sstride + wave;
-      if (work < w_end && (!NODEW || wave < NE)) {
+      bool item_on = work < w_end && (!NODEW || wave < NE);
+      if constexpr (!F16 && !FIN) {      // the exact kernels as AUTO's fp32 repeat: items without a centre of a flagged structure are skipped
+          if (item_on && only_fl) item_on = rows_flagged(flags, work * A, A, N1, lane);
+      }
+      if (item_on) {
         const int c0 = work * A;
         if constexpr (M32) {
             TRACE32(19);
@@ -3185,7 +3207,7 @@ void launch_node(hipStream_t st, const float* W, const LayerW* finish, const Lay
     const LayerW& wp = prep ? *prep : dummy;
     if (variant == 1) {
         hipLaunchKernelGGL(k_node, dim3((chunk + 3) / 4 * 8), dim3(256), 0, st, W, wf, wp, finish ? 1 : 0, prep ? 1 : 0, N1, q_state, p_state, Z,
-                           rec_nb, rec_cen);
+                           rec_nb, rec_cen, (const int*)flags);
         return;
     }
     // eight waves = two tiles per iteration; persistent workgroups, at most one per CU (32 per XCD)
