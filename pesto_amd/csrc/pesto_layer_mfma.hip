@@ -688,13 +688,16 @@ __device__ unsigned long long g_phase_cycles[12];
 #define TRACE32(id) do {} while (0)
 #define P32_MARK(k) do {} while (0)
 #endif
-struct alignas(16) EdgeWaveScratch {      // 16-byte multiple: the rows are read / written as float4 (ds_read / ds_write_b128)
-    int nb[64];          // neighbour id per row
-    float geo[5][64];    // r_hat x, y, z, d per row (SoA); row 4 = 1.0 (k = 3 slot of the centre MFMA's B operand)
-    float wts[8][64];    // attention weights [h*4 + part][row]: part 0 scalar, 1..3 the vector chunks
+// ROWS = edge rows of a work item: 64, or 16 for the one-tile items of the sixteen-wave node-wave workgroups (twelve item waves: LDS)
+template <int ROWS>
+struct alignas(16) EdgeWaveScratchT {      // 16-byte multiple: the rows are read / written as float4 (ds_read / ds_write_b128)
+    int nb[ROWS];          // neighbour id per row
+    float geo[5][ROWS];    // r_hat x, y, z, d per row (SoA); row 4 = 1.0 (k = 3 slot of the centre MFMA's B operand)
+    float wts[8][ROWS];    // attention weights [h*4 + part][row]: part 0 scalar, 1..3 the vector chunks
     float wsum[8][2];    // per centre: sum over edges of the part-2 weights (multiplies p_i)
     float z3buf[2][2][96];  // [centre sel][h][c*32+s]: sum_e w3[h][e] p_j(e), staged for the final combine
 };
+using EdgeWaveScratch = EdgeWaveScratchT<64>;
 // per-wave scratch of the 32-edge-tile kernel (M32, further down)
 struct alignas(16) EdgeWaveScratch32 {
     int nb[64];               // neighbour id per row of the work item
@@ -714,14 +717,14 @@ constexpr int XCH_FLOATS = 3072;
 // NE = waves that process work items. NE == WPB: every wave does, the finish / prepare phase runs behind workgroup rendezvous.
 // NE < WPB ("node waves"): the other WPB - NE waves ONLY finish / prepare, fed through LDS queues without any workgroup barrier:
 // two generations of staged Z rows per edge wave and of the 16-centre state exchange.
-constexpr int XF_POST = 0, XF_READY = 2, XF_CONSUMED = 4;      // xflag slots: slices posted per tile | rows staged per generation | generations read
-template <int WPB, bool HY, bool XCH = false, int NE = WPB, bool M32 = false>
+constexpr int XF_POST = 0, XF_READY = 2, XF_CONSUMED = 4, XF_READY2 = 6;      // xflag slots: slices posted per tile | rows staged per generation | generations read
+template <int WPB, bool HY, bool XCH = false, int NE = WPB, bool M32 = false, int ROWS = 64>
 struct EdgeSmem {
     static constexpr int GEN = (XCH && NE < WPB) ? 2 : 1;
     float w[M32 ? EDGE_LDS_FLOATS_32 : HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS];
-    typename std::conditional<M32, EdgeWaveScratch32, EdgeWaveScratch>::type ws[NE];
+    typename std::conditional<M32, EdgeWaveScratch32, EdgeWaveScratchT<ROWS>>::type ws[NE];
     float zrows[NE][GEN][2][256];   // Zq | Zp staging per centre: two rows per edge wave (and generation)
-    float xch[XCH ? (NE < WPB ? 2 * 2048 : XCH_FLOATS) : 4];
+    float xch[XCH ? (NE < WPB ? (WPB - NE) / 4 * 2 * 2048 : XCH_FLOATS) : 4];      // (node waves: two generations per team)
     // bias of the value network's last layer, four copies per feature: the accumulator tile of feature column e starts as (b, b, b, b) -
     // one ds_read_b128 instead of a 4-byte read + four v_mov per block (16 v_mov per tile). Filled by the kernel's prologue.
     alignas(16) float b3v4[(HY && !M32) ? 256 : 4];
@@ -775,8 +778,8 @@ __device__ __forceinline__ f32x4 l1_compute(const L1Ops& o, int fb, int g, float
 // per-tile addressing: centre record(s), neighbour record of this lane's edge, geometry
 struct TileCtx { const float *cenA, *cenB, *recj, *recj_p; float rx, ry, rz, d, bgA, bgB; };
 
-template <int NN, bool HY = false>
-__device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1, const EdgeWaveScratch& ws,
+template <int NN, bool HY = false, class WS = EdgeWaveScratch>
+__device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1, const WS& ws,
                                             const float* __restrict__ rec_nb, const float* __restrict__ rec_cen) {
     TileCtx c;
     const int row = 16 * t + e;
@@ -822,8 +825,8 @@ __device__ __forceinline__ f32x4 to_mfma_lanes(f32x4 v, int lane) {
 struct L1Raw { f32x4 x0, x1, y0, y1, z0, z1, a4[4]; float cA[4], cB[4]; };
 struct L1Head { f16x8 fh, fl; f32x4 acc[4]; float d; };
 
-template <int NN>
-__device__ __forceinline__ L1Raw l1_issue(int fb0, int t, int lane, const TileCtx& tc, const EdgeWaveScratch& ws,
+template <int NN, class WS = EdgeWaveScratch>
+__device__ __forceinline__ L1Raw l1_issue(int fb0, int t, int lane, const TileCtx& tc, const WS& ws,
                                           const float* __restrict__ p_state) {
     L1Raw r;
     const int rp = 16 * t + (lane >> 2);               // producer lane: edge rp, piece prod_piece(lane) (32 bytes of p_j, 16 of A_j)
@@ -839,8 +842,8 @@ __device__ __forceinline__ L1Raw l1_issue(int fb0, int t, int lane, const TileCt
     return r;
 }
 
-template <int NN>
-__device__ __forceinline__ L1Head l1_head(const L1Raw& r, int t, int lane, const TileCtx& tc, const EdgeWaveScratch& ws) {
+template <int NN, class WS = EdgeWaveScratch>
+__device__ __forceinline__ L1Head l1_head(const L1Raw& r, int t, int lane, const TileCtx& tc, const WS& ws) {
     L1Head o;
     const int rp = 16 * t + (lane >> 2);
     // p_j(ep) . r_hat(ep) for s = 8 chunk .. 8 chunk + 7 (model_operations.py:115), split, moved to the MFMA lane layout
@@ -1523,9 +1526,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     // one-centre items), which halves the number of workgroup rendezvous
     constexpr int SUBS = FIN ? 2 / A : 1;
     constexpr bool NODEW = FIN && NE < WPB;      // node-wave mode: waves NE.. finish / prepare only
-    static_assert(NE == WPB || (FIN && WPB - NE == 4 && NE * A * SUBS == 16), "node waves: four of them, one 16-centre tile per iteration");
+    // node-wave mode: four node waves; eight item waves (one 16-centre tile per iteration) or - sixteen-wave workgroups, one-tile items,
+    // 128 registers: FOUR waves per SIMD, three of them on work items - twelve (24 centres per iteration: one full tile + one half tile)
+    static_assert(NE == WPB || (FIN && WPB - NE == 4 && (NE * A * SUBS == 16 || (NE == 12 && TI == 1 && A * SUBS == 2))) || (FIN && WPB - NE == 8 && NE * A * SUBS == 16),
+                  "node waves: four of them (16 or 24 centres per iteration), or two teams of four that take the iterations in turn");
+    constexpr int NTEAM = (FIN && NE < WPB) ? (WPB - NE) / 4 : 1;
+    constexpr int NWT = NODEW ? (NE * A * SUBS + 15) / 16 : 1;      // 16-centre tiles of an iteration (node-wave mode)
+    constexpr int WROWS = (NODEW && (NE > 8 || WPB - NE == 8)) ? 16 * TI : 64;          // rows of the per-wave scratch (sixteen-wave workgroups: LDS)
     static_assert(!M32 || (HY && NE == WPB && WPB == 8 && NN >= 16 && TI % 2 == 0), "M32: eight-wave workgroups, whole 32-edge tiles");
-    __shared__ EdgeSmem<WPB, HY, FIN, NE, M32> sm;
+    __shared__ EdgeSmem<WPB, HY, FIN, NE, M32, WROWS> sm;
     int tr_n = 0;           // (developer builds: timeline of one wave)
     (void)tr_n;
     TRACE32(NN == 8 ? 60 : NN == 16 ? 61 : NN == 32 ? 62 : 63);
@@ -1566,9 +1575,11 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         if (first_item) {     // rows of the first item -> the wave's scratch (no register survives into the work loop)
             auto& ws0 = sm.ws[threadIdx.x >> 6];
             const int l0 = threadIdx.x & 63;
-            ws0.nb[l0] = first_valid ? first_nb : 0;
-            ws0.geo[0][l0] = first_valid ? first_geo.x : 0.f; ws0.geo[1][l0] = first_valid ? first_geo.y : 0.f;
-            ws0.geo[2][l0] = first_valid ? first_geo.z : 0.f; ws0.geo[3][l0] = first_valid ? first_geo.w : 0.f; ws0.geo[4][l0] = 1.0f;
+            if (WROWS == 64 || l0 < WROWS) {
+                ws0.nb[l0] = first_valid ? first_nb : 0;
+                ws0.geo[0][l0] = first_valid ? first_geo.x : 0.f; ws0.geo[1][l0] = first_valid ? first_geo.y : 0.f;
+                ws0.geo[2][l0] = first_valid ? first_geo.z : 0.f; ws0.geo[3][l0] = first_valid ? first_geo.w : 0.f; ws0.geo[4][l0] = 1.0f;
+            }
         }
     }
     __syncthreads();
@@ -1612,7 +1623,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
       const int sstride = tail ? nbx * NE : NE;
       const int base = it_start + jb * NE * (tail ? 1 : SUBS);
       // node-wave mode: this generation of staging rows was last used two iterations ago - the node waves must have read it
-      if (NODEW && wave < NE && fin_iter >= 2) lds_wait_ge(&sm.xflag[XF_CONSUMED], 4 * (fin_iter - 1));
+      if (NODEW && wave < NE && fin_iter >= 2) {
+          if (NTEAM == 2) lds_wait_ge(&sm.xflag[XF_CONSUMED + (fin_iter & 1)], 4 * (fin_iter >> 1));      // (one counter per generation = per team)
+          else lds_wait_ge(&sm.xflag[XF_CONSUMED], 4 * NWT * (fin_iter - 1));
+      }
 #pragma unroll 1
       for (int sub = 0; sub < SUBS; ++sub) {
       const int work = base + sub * sstride + wave;
@@ -1663,9 +1677,11 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             const size_t src = (size_t)min(i, N1 - 1) * KMAX + c;           // unconditional loads, select afterwards
             const int nbv = ids_s[src];
             const float4 gg = geo[src];
-            ws.nb[lane] = valid ? nbv : 0;
-            ws.geo[0][lane] = valid ? gg.x : 0.f; ws.geo[1][lane] = valid ? gg.y : 0.f; ws.geo[2][lane] = valid ? gg.z : 0.f;
-            ws.geo[3][lane] = valid ? gg.w : 0.f; ws.geo[4][lane] = 1.0f;
+            if (WROWS == 64 || lane < WROWS) {
+                ws.nb[lane] = valid ? nbv : 0;
+                ws.geo[0][lane] = valid ? gg.x : 0.f; ws.geo[1][lane] = valid ? gg.y : 0.f; ws.geo[2][lane] = valid ? gg.z : 0.f;
+                ws.geo[3][lane] = valid ? gg.w : 0.f; ws.geo[4][lane] = 1.0f;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         PHASE_MARK(0);
@@ -2944,32 +2960,46 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const int gen = fin_iter & 1;
         if (wave_u < NE) {
-            lds_signal(&sm.xflag[XF_READY + gen], lane == 0);
+            // (twelve item waves: the waves of the second, half-filled tile count in a counter of their own - the node waves start on the
+            // first tile as soon as ITS eight waves have staged)
+            lds_signal(&sm.xflag[((NWT > 1 && wave_u >= 8) ? XF_READY2 : XF_READY) + gen], lane == 0);
         } else {
-            const int role = wave_u - NE;
+            // (two teams: team t takes the iterations of generation t - a tile's chain may then last two iterations)
+            const int role = (wave_u - NE) & 3;
             const bool prep = rec_cen_out != nullptr;
-            const int fe = lane & 15, fg = lane >> 4;
-            // centre of MFMA column fe: edge wave fe / CPW, its staged row fe % CPW (work-item arithmetic of the loop above)
-            const int cw = fe / CPW, cr = fe % CPW;
+            const int tq = NTEAM == 2 ? gen : 0;          // counters / exchange buffer of this team
+#pragma unroll 1
+          for (int ntile = 0; ntile < ((NTEAM == 2 && ((wave_u - NE) >> 2) != gen) ? 0 : NWT); ++ntile) {
+            // (several tiles per iteration: the lane index is re-derived per tile from an opaque copy - as invariants of this loop the weight
+            // fragments of the whole phase would be loaded once in front of it and live across it)
+            int lane_n = lane;
+            if (NWT > 1) asm volatile("" : "+v"(lane_n));
+            const int fe = lane_n & 15, fg = lane_n >> 4;
+            // centre of MFMA column fe: edge wave fe / CPW (+ 16 / CPW per tile), its staged row fe % CPW (work-item arithmetic of the loop above)
+            const int cw_raw = ntile * (16 / CPW) + fe / CPW, cr = fe % CPW;
+            const int cw = NWT > 1 ? min(cw_raw, NE - 1) : cw_raw;
             const int cwork = base + (SUBS > 1 ? cr * sstride : 0) + cw;
             const int ci_raw = cwork * A + (SUBS > 1 ? 0 : cr);
-            const bool valid = cwork < w_end && ci_raw < N1;
+            const bool valid = cwork < w_end && ci_raw < N1 && cw_raw < NE;
             const int ci = valid ? ci_raw : 0;
             const float* zr = sm.zrows[cw][gen][cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
             const float st_limit = state_limit_of(flags);      // conditioning trigger
-            const float* fb = W + lw.h_q0 + lane * 4;       // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
-            float* xs = sm.xch + gen * 2048;                // [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column 16][4]
+            const float* fb = W + lw.h_q0 + lane_n * 4;       // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
+            const int ntile_seq = fin_iter * NWT + ntile;   // tiles this workgroup's node waves have taken before this one
+            // exchange buffer, two generations (a wave posts its next tile while a slower wave of its team still reads this one)
+            float* xs = sm.xch + (NTEAM == 2 ? 2 * tq + ((fin_iter >> 1) & 1) : (ntile_seq & 1)) * 2048;    // [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column 16][4]
             float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
             f16x8 zh[2], zl[2];
-            auto rows = [&]() {                 // wait for the eight edge waves, then this role's part of the 16 rows as hi/lo B operands
-                lds_wait_ge<16>(&sm.xflag[XF_READY + gen], NE * ((fin_iter >> 1) + 1));
+            auto rows = [&]() {                 // wait for the tile's edge waves, then this role's part of the 16 rows as hi/lo B operands
+                if (NWT > 1 && ntile == 1) lds_wait_ge<16>(&sm.xflag[XF_READY2 + gen], (NE - 8) * ((fin_iter >> 1) + 1));
+                else lds_wait_ge<16>(&sm.xflag[XF_READY + gen], (NE < 8 ? NE : 8) * ((fin_iter >> 1) + 1));
 #pragma unroll
                 for (int kgp = 0; kgp < 2; ++kgp) {
                     f32x4 a0 = ld4(zr + 32 * kgp + 4 * fg), a1 = ld4(zr + 32 * kgp + 16 + 4 * fg);
                     if (!valid) { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }     // unused columns: no stale LDS bits into the range guard
                     split8(a0, a1, zh[kgp], zl[kgp]);
                 }
-                lds_signal(&sm.xflag[XF_CONSUMED], lane == 0);
+                lds_signal(&sm.xflag[XF_CONSUMED + tq], lane_n == 0);
 #ifdef PESTO_NODEW_PRIO      // (developer: priority of a node wave while it computes; it polls at priority 0)
                 __builtin_amdgcn_s_setprio(PESTO_NODEW_PRIO);
 #endif
@@ -2977,7 +3007,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             auto post = [&](const f32x4* v) {
                 st4(xs + ((2 * role) * 4 + fg) * 64 + fe * 4, v[0]);
                 st4(xs + ((2 * role + 1) * 4 + fg) * 64 + fe * 4, v[1]);
-                lds_signal(&sm.xflag[XF_POST], lane == 0);
+                lds_signal(&sm.xflag[XF_POST + tq], lane_n == 0);
             };
 #define PESTO_FIN_MFMA(acc, fr, xh_, xl_)                                                   \
     {                                                                                        \
@@ -2985,6 +3015,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xl_, acc[m]);     \
         _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m + 1], xh_, acc[m]); \
     }
+#ifdef PESTO_ABL_NONODE      // ablation (results wrong): the node waves only keep the queues moving - what the item waves cost by themselves
+            rows();
+            sat_probe(sat, __builtin_bit_cast(float, (int)zh[0][0]));
+            lds_signal(&sm.xflag[XF_POST + tq], lane_n == 0);
+            continue;
+#endif
             f32x4 st[2];
             if (role == 0) {   // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147, :151)
                 f16x8 w0[2][4], w1[4], w2[4];            // [kgp][(m, hi|lo)], [(m, hi|lo)]
@@ -3040,7 +3076,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 if (role != 0) {   // G[c] blocks 0..7 straight from the own slice p[c], c = role - 1
                     f16x8 ph, pl;
                     split8(st[0], st[1], ph, pl);
-                    const float* Lgc = W + lwp.h_gc + lane * 4;
+                    const float* Lgc = W + lwp.h_gc + lane_n * 4;
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         f16x8 gw[4][2];
@@ -3065,7 +3101,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 f16x8 ua[2][4][2];                    // [kgp][block][hi|lo]
                 f32x4 ub[4];
                 {
-                    const float* Lua = W + lwp.h_ua + lane * 4;          // [m 16][kgp 2][hi|lo][256]
+                    const float* Lua = W + lwp.h_ua + lane_n * 4;          // [m 16][kgp 2][hi|lo][256]
 #pragma unroll
                     for (int kgp = 0; kgp < 2; ++kgp)
 #pragma unroll
@@ -3076,7 +3112,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ub[j] = ob < 8 ? ld4(W + lwp.n_b1s + 16 * (ob + j) + 4 * fg) : f32x4{0, 0, 0, 0};
                 }
-                lds_wait_ge(&sm.xflag[XF_POST], 4 * fin_iter + 4);
+                lds_wait_ge(&sm.xflag[XF_POST + tq], NTEAM == 2 ? 4 * (fin_iter >> 1) + 4 : 4 * ntile_seq + 4);
                 f16x8 xnh[2], xnl[2];
                 {   // [q | ||p||] of the tile as f16 hi/lo B operands (k-group 0 = q, 1 = ||p||)
                     f32x4 q[2], pn[2];
@@ -3116,7 +3152,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     }
                 }
                 if (role == 0) {   // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12                        (:119)
-                    const float* nq = W + lwp.h_n0 + lane * 4;     // fragments n0 [m 2][kgp 2] | n1 [m 2] | n2 [1], (hi, lo) pairs of 256 floats
+                    const float* nq = W + lwp.h_n0 + lane_n * 4;     // fragments n0 [m 2][kgp 2] | n1 [m 2] | n2 [1], (hi, lo) pairs of 256 floats
                     f16x8 n0[2][4], n1[4], n2[2];
                     f32x4 hq[2], tq[2], qq[1];
 #pragma unroll
@@ -3148,6 +3184,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #ifdef PESTO_NODEW_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
+          }      // ntile
         }
         ++fin_iter;
       }
@@ -3274,7 +3311,20 @@ static double rounds_paid(int n_work, int waves, int subs) {
     const double tail = rest <= 0.0 ? 0.0 : (subs == 2 && rest <= 0.5) ? 0.5 : 1.0;
     return (full + tail) * round;
 }
+// NW16 (round 5, measured and NOT shipped; profiles/r05_nw16_ab.txt): SIXTEEN-wave node-wave workgroups for the nn = 8 layer at 128
+// registers (four waves per SIMD; the kernel fits: 1 - 8 registers spilled), in two forms -
+//   -DPESTO_NW16_ITEMS12: twelve item waves + four node waves (three item waves per SIMD; 24 centres per iteration = one full and one half
+//       tile for the node waves; 16-row per-wave scratch for the LDS). Item waves alone (node work ablated) 49.9 -> 46.6 us per launch: a
+//       third item wave per SIMD buys 7 %, not the 1 / 3 a latency-bound chain would give - and with the node work the launch takes 78 us
+//       against 59: the four node waves cannot finish two tiles per iteration;
+//   -DPESTO_NW16: eight item waves + TWO TEAMS of four node waves that take the iterations in turn: 59.9 -> 58.7 us per launch; the node
+//       work costs 5 us instead of 9, the four extra (polling) waves cost the item waves 4 (item waves alone 49.9 -> 53.8).
+// Both give the same bits as the twelve-wave form. What the nn = 8 layer pays for the node work (9 of 59 us) is contention for issue
+// slots and the L1, neither the depth of the item chain nor the length of the node chain: DESIGN 4.1h.
 static bool node_wave_mode(int nn, int n_work) {
+#ifdef PESTO_NW16_ITEMS12
+    if (nn == 8) return true;                                      // same round as the rendezvous mode (256 x 12 x 2 centres)
+#endif
     const int subs = nn == 64 ? 2 : 1;                                     // items per wave and iteration (two staged centres per wave)
     const double cost = nn == 8 ? 0.87 : nn == 16 ? 0.94 : nn == 32 ? 0.95 : 1.023;      // (re-measured in round 5: nn = 8 56.1 vs 66.9, nn = 16 86.1 vs 91.6, nn = 32 with one pass per tile 144.4 vs 152.2 us)
     return rounds_paid(n_work, 8, subs) * cost < rounds_paid(n_work, 12, subs);
@@ -3304,7 +3354,13 @@ static void launch_edge_full(hipStream_t st, const float* W, const LayerW& lw, i
     const int a = lw.nn == 64 ? 1 : 2;                                     // centres per wave and work step (nn = 8: one-tile items of two centres; nn = 16 node-wave mode: two one-centre items)
     const bool nw = mode == 0 ? node_wave_mode(lw.nn, (N1 + a - 1) / a) : mode == 2;
     switch (lw.nn) {
+#if defined(PESTO_NW16_ITEMS12)
+        case 8: if (nw) launch_edge_k<8, 16, false, true, true, 1, true, 12>(st, W, lw, N1, io, max_blocks);
+#elif defined(PESTO_NW16)
+        case 8: if (nw) launch_edge_k<8, 16, false, true, true, 1, true, 8>(st, W, lw, N1, io, max_blocks);
+#else
         case 8: if (nw) launch_edge_k<8, 12, false, true, true, 1, true, 8>(st, W, lw, N1, io, max_blocks);
+#endif
                 else launch_edge_k<8, 12, false, true, true, 1, true>(st, W, lw, N1, io, max_blocks);
                 break;
         // nn = 16, node-wave mode (round 5): ONE-tile items, two per wave and iteration, instead of one two-tile item - a one-tile item reuses
