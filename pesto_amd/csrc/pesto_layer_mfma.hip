@@ -2964,6 +2964,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             // first tile as soon as ITS eight waves have staged)
             lds_signal(&sm.xflag[((NWT > 1 && wave_u >= 8) ? XF_READY2 : XF_READY) + gen], lane == 0);
         } else {
+            // weight fragments of the node waves: plain global loads, or (-DPESTO_NODEW_WAUX=<aux>, developer) buffer loads with cache-policy bits
+            // (gfx950: 1 = sc0, 2 = nt, 16 = sc1) - the 166 KB stream per 16 centres goes through the 32 KB L1 the gathers live in
+#ifdef PESTO_NODEW_WAUX
+            const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W);
+#define LDW(ptr) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(((ptr) - W) * 4), 0, PESTO_NODEW_WAUX))
+#else
+#define LDW(ptr) ld8h(ptr)
+#endif
             // (two teams: team t takes the iterations of generation t - a tile's chain may then last two iterations)
             const int role = (wave_u - NE) & 3;
             const bool prep = rec_cen_out != nullptr;
@@ -3028,9 +3036,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp) { w0[kgp][2 * m] = ld8h(fb + ((m * 2 + kgp) * 2) * 256); w0[kgp][2 * m + 1] = ld8h(fb + ((m * 2 + kgp) * 2 + 1) * 256); }
+                    for (int kgp = 0; kgp < 2; ++kgp) { w0[kgp][2 * m] = LDW(fb + ((m * 2 + kgp) * 2) * 256); w0[kgp][2 * m + 1] = LDW(fb + ((m * 2 + kgp) * 2 + 1) * 256); }
 #pragma unroll
-                for (int f = 0; f < 4; ++f) { w1[f] = ld8h(fb + (8 + f) * 256); w2[f] = ld8h(fb + (12 + f) * 256); }
+                for (int f = 0; f < 4; ++f) { w1[f] = LDW(fb + (8 + f) * 256); w2[f] = LDW(fb + (12 + f) * 256); }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     h[m] = ld4(W + lw.n_bq0 + 16 * m + 4 * fg); b1v[m] = ld4(W + lw.n_bq1 + 16 * m + 4 * fg); b2v[m] = ld4(W + lw.n_bq2 + 16 * m + 4 * fg);
@@ -3053,7 +3061,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp) { wp[kgp][2 * m] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2) * 256); wp[kgp][2 * m + 1] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2 + 1) * 256); }
+                    for (int kgp = 0; kgp < 2; ++kgp) { wp[kgp][2 * m] = LDW(fb + 4096 + ((m * 2 + kgp) * 2) * 256); wp[kgp][2 * m + 1] = LDW(fb + 4096 + ((m * 2 + kgp) * 2 + 1) * 256); }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) st[m] = ld4(p_state + (size_t)ci * 96 + (role - 1) * 32 + 16 * m + 4 * fg);
                 rows();
@@ -3082,7 +3090,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         f16x8 gw[4][2];
                         f32x4 a[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { gw[j][0] = ld8h(Lgc + ((4 * half + j) * 2) * 256); gw[j][1] = ld8h(Lgc + ((4 * half + j) * 2 + 1) * 256); a[j] = f32x4{0, 0, 0, 0}; }
+                        for (int j = 0; j < 4; ++j) { gw[j][0] = LDW(Lgc + ((4 * half + j) * 2) * 256); gw[j][1] = LDW(Lgc + ((4 * half + j) * 2 + 1) * 256); a[j] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[j][0], ph, a[j]);
 #pragma unroll
@@ -3107,7 +3115,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float* fr = Lua + (size_t)(((ob + j) * 2 + kgp) * 2) * 256;
-                            ua[kgp][j][0] = ld8h(fr); ua[kgp][j][1] = ld8h(fr + 256);
+                            ua[kgp][j][0] = LDW(fr); ua[kgp][j][1] = LDW(fr + 256);
                         }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ub[j] = ob < 8 ? ld4(W + lwp.n_b1s + 16 * (ob + j) + 4 * fg) : f32x4{0, 0, 0, 0};
@@ -3158,10 +3166,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int kgp = 0; kgp < 2; ++kgp) { n0[kgp][2 * m] = ld8h(nq + ((m * 2 + kgp) * 2) * 256); n0[kgp][2 * m + 1] = ld8h(nq + ((m * 2 + kgp) * 2 + 1) * 256); }
+                        for (int kgp = 0; kgp < 2; ++kgp) { n0[kgp][2 * m] = LDW(nq + ((m * 2 + kgp) * 2) * 256); n0[kgp][2 * m + 1] = LDW(nq + ((m * 2 + kgp) * 2 + 1) * 256); }
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) n1[f] = ld8h(nq + (8 + f) * 256);
-                    n2[0] = ld8h(nq + 12 * 256); n2[1] = ld8h(nq + 13 * 256);
+                    for (int f = 0; f < 4; ++f) n1[f] = LDW(nq + (8 + f) * 256);
+                    n2[0] = LDW(nq + 12 * 256); n2[1] = LDW(nq + 13 * 256);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) { hq[m] = ld4(W + lwp.n_bn0 + 16 * m + 4 * fg); tq[m] = ld4(W + lwp.n_bn1 + 16 * m + 4 * fg); }
                     qq[0] = ld4(W + lwp.n_bn2 + 4 * fg);
@@ -3185,6 +3193,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             __builtin_amdgcn_s_setprio(0);
 #endif
           }      // ntile
+#undef LDW
         }
         ++fin_iter;
       }
