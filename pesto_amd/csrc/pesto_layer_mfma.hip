@@ -1613,7 +1613,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
       // thread index: as loop invariants they would stay in registers across the finish / prepare phase below, which needs them for
       // weight fragments (forty registers; the fragments of that phase otherwise spill in front of its rendezvous)
       int tid_i = threadIdx.x;
+      // (-DPESTO_HOIST_NW, measured and dropped: in node-wave mode the item waves have no finish phase, so only the node waves' lane index
+      // needs to be opaque; the nn = 8 item block shrinks by 54 of 894 instructions, the kernel needs all 168 registers, reloads two values
+      // from scratch per tile - and is 2 % SLOWER, 57.9 -> 59.2 us per launch: profiles/r05_nw16_ab.txt)
+#ifdef PESTO_HOIST_NW
+      if (FIN && !NODEW) asm volatile("" : "+v"(tid_i));
+#else
       if (FIN) asm volatile("" : "+v"(tid_i));
+#endif
       const int lane = tid_i & 63, wave = tid_i >> 6;
       const int e = lane & 15, g = lane >> 4;
       const int wslot = (NODEW && wave >= NE) ? 0 : wave;      // (node waves never touch the per-wave scratch)
@@ -2981,7 +2988,11 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             // (several tiles per iteration: the lane index is re-derived per tile from an opaque copy - as invariants of this loop the weight
             // fragments of the whole phase would be loaded once in front of it and live across it)
             int lane_n = lane;
+#ifdef PESTO_HOIST_NW
+            asm volatile("" : "+v"(lane_n));
+#else
             if (NWT > 1) asm volatile("" : "+v"(lane_n));
+#endif
             const int fe = lane_n & 15, fg = lane_n >> 4;
             // centre of MFMA column fe: edge wave fe / CPW (+ 16 / CPW per tile), its staged row fe % CPW (work-item arithmetic of the loop above)
             const int cw_raw = ntile * (16 / CPW) + fe / CPW, cr = fe % CPW;
