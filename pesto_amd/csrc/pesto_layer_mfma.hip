@@ -1505,6 +1505,16 @@ __device__ __forceinline__ void edge_item32(EdgeWaveScratch32& ws, const float* 
 // the matrix cores - role 0: q += qpm(Zq), roles 1..3: p[c] += ppm(Zp[c]) (model_operations.py:147-152), sink reset (:239-240) -
 // with the weight fragments streamed from L2, and write the NEW state into the other half of a ping-pong pair (neighbours'
 // p_j of the old state are still being gathered by other workgroups). The node kernel then only prepares records.
+// s_setprio takes an immediate: one scalar branch per age class (the class is wave-uniform, in an SGPR)
+template <int P0, int P1, int P2>
+__device__ __forceinline__ void prio_by_age(int cls) {
+    if constexpr (P0 == P1 && P1 == P2) { __builtin_amdgcn_s_setprio(P0); }
+    else {
+        if (cls == 0) __builtin_amdgcn_s_setprio(P0);
+        else if (cls == 1) __builtin_amdgcn_s_setprio(P1);
+        else __builtin_amdgcn_s_setprio(P2);
+    }
+}
 template <int NN, int WPB, bool PF, bool F16, bool HY = false, int TI = 4, bool FIN = false, int NE = WPB, bool M32 = false>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const float* __restrict__ W, LayerW lw, int N1, int n_work,
                                                  const int* __restrict__ ids_s, const float4* __restrict__ geo,
@@ -1623,6 +1633,32 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #endif
       const int lane = tid_i & 63, wave = tid_i >> 6;
       const int e = lane & 15, g = lane >> 4;
+      // wave priority by age class (waves 0-3 / 4-7 / 8-11 of a workgroup = oldest / middle / youngest wave of their SIMD). At equal
+      // priority the arbiter prefers the oldest wave: in a full nn = 64 launch wave 0 reaches the rendezvous of its twelve-wave workgroup
+      // 20 - 28 thousand cycles (~25 % of an iteration) ahead of the slowest wave and its SIMD runs on two waves for that long. The
+      // priority of a wave's MFMA bursts therefore grows with its youth (1 / 2 / 3; outside the bursts 0 for everybody, as before):
+      // nn = 64 -1.2 ... -2.5 % per launch on three boxes (profiles/r05_prio_age_ab.txt); the reverse order (3, 2, 1), a raised base level
+      // for the young waves and the same table on the one-tile items' two-pass path (nn = 8 / 16) gain nothing. Scheduling only: same bits.
+      // -DPESTO_PRIO_HI_TAB=1,1,1 builds the uniform priorities of rounds 1 - 5.
+#ifndef PESTO_PRIO_HI_TAB
+#define PESTO_PRIO_HI_TAB 1, 2, 3
+#endif
+#ifndef PESTO_PRIO_LO_TAB
+#define PESTO_PRIO_LO_TAB 0, 0, 0
+#endif
+      const int wave_p = __builtin_amdgcn_readfirstlane(wave) >> 2;
+      (void)wave_p;
+#define PESTO_PRIO_HI() prio_by_age<PESTO_PRIO_HI_TAB>(wave_p)
+#define PESTO_PRIO_LO() prio_by_age<PESTO_PRIO_LO_TAB>(wave_p)
+      // (the two-pass path: one-tile items of nn = 8 / 16, the exact kernels)
+#ifndef PESTO_PRIO_HI2_TAB
+#define PESTO_PRIO_HI2_TAB 1, 1, 1
+#endif
+#ifndef PESTO_PRIO_LO2_TAB
+#define PESTO_PRIO_LO2_TAB 0, 0, 0
+#endif
+#define PESTO_PRIO_HI2() prio_by_age<PESTO_PRIO_HI2_TAB>(wave_p)
+#define PESTO_PRIO_LO2() prio_by_age<PESTO_PRIO_LO2_TAB>(wave_p)
       const int wslot = (NODEW && wave >= NE) ? 0 : wave;      // (node waves never touch the per-wave scratch)
       auto& ws = sm.ws[wslot];
       float (*zrow)[256] = sm.zrows[wslot][NODEW ? (fin_iter & 1) : 0];
@@ -1856,10 +1892,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     float lgt[2];
                     {
                         f32x4 h1[4];
-                        __builtin_amdgcn_s_setprio(1);
+                        PESTO_PRIO_HI();
                         l1_tail(hd, 0, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
                         keys_of_tile(t, h1, lgt);
-                        __builtin_amdgcn_s_setprio(0);
+                        PESTO_PRIO_LO();
                     }
                     // unnormalised attention weights of this tile (same table layout as the two-pass code), row sums per lane
 #pragma unroll
@@ -1882,7 +1918,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     f32x4 h1v[4];
                     {
                         L1Head hv = l1_head_ac<NN>(rac, keep_h, keep_l, lane, tcc);
-                        __builtin_amdgcn_s_setprio(1);
+                        PESTO_PRIO_HI();
                         l1_tail(hv, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1v, sat);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1958,7 +1994,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                             for (int fo = 0; fo < 2; ++fo) v[f0 + fo] = MFMA16(ah, bl[fo], v[f0 + fo]);
                         }
                     }
-                    __builtin_amdgcn_s_setprio(0);
+                    PESTO_PRIO_LO();
                     if constexpr (W3SPLIT) {
                         const f32x4 w0 = ld4(&ws.wts[3][16 * t + 8 * (esub & 1) + 4]), w1 = ld4(&ws.wts[7][16 * t + 8 * (esub & 1) + 4]);
 #pragma unroll
@@ -2092,7 +2128,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                         f32x4 h1[4];
                         // wave priority: a wave inside its MFMA burst (first-layer tail, key / value networks) goes ahead of waves that are in
                         // VALU / LDS phases (softmax, weighted sums, finalize) - measured +3.8 % (levels 1..3 alike)
-                        __builtin_amdgcn_s_setprio(1);
+                        PESTO_PRIO_HI2();
                         l1_tail(hd, 0, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
                         keys_of_tile(t, h1);
                         if constexpr (VFIRST) {      // (t == 0: a one-tile item)
@@ -2149,7 +2185,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                                 }
                             }
                         }
-                        __builtin_amdgcn_s_setprio(0);
+                        PESTO_PRIO_LO2();
                         if constexpr (VFIRST) {      // the first half of the tile's p_j gathers for the part-3 sums: in flight during the softmax
                             const int esub0 = lane >> 5, quad0 = (lane & 31) < 24 ? (lane & 31) : (lane & 31) - 24;
                             int nbj[4];
@@ -2354,7 +2390,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     __builtin_amdgcn_sched_barrier(0);
                     hd = l1_head<NN>(raw, t, lane, tc, ws);
                 }
-                __builtin_amdgcn_s_setprio(1);
+                PESTO_PRIO_HI2();
                 l1_tail(hd, 4, lane, g, sm.w + EL_W1P, sm.w + EL_WD, h1, sat);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -2479,7 +2515,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             }
             }      // !VFIRST
             PHASE_MARK(4);
-            __builtin_amdgcn_s_setprio(0);
+            PESTO_PRIO_LO2();
             if constexpr (W3SPLIT) {
                 const f32x4 w0 = ld4(&ws.wts[3][16 * t + 8 * (esub & 1) + 4]), w1 = ld4(&ws.wts[7][16 * t + 8 * (esub & 1) + 4]);   // edges 8 + 2 i2 + parity
 #pragma unroll
