@@ -381,6 +381,36 @@ __global__ __launch_bounds__(256) void k_node(const float* __restrict__ W, Layer
 // NM output blocks advanced through k-group kgp (two 16-feature input blocks) on v_mfma_f32_16x16x32_f16 with both
 // operands split into f16 hi/lo pairs: acc += wh*xh + wh*xl + wl*xh  (the dropped wl*xl term is ~2^-22 relative).
 // Fragment table layout: [m][kgroup][hi|lo][lane][8 halves] (pesto_schema.cpp::put_frags_f16).
+// Layer constants -> LDS: all of a thread's loads of a batch are issued before its first store. Written as a plain loop the copy is load -
+// wait - store per 16 bytes: one dependent L2 round trip per pass over the workgroup (six to eight in front of every edge launch's first
+// work item, twelve in k_node16: 5,200 - 6,100 cycles by the one-wave timeline; one structure per call 0.832 -> 0.811 ms, profiles/
+// r05_prologue_ab.txt). Batches of at most eight loads (32 registers, prologue only). -DPESTO_SERIAL_PROLOGUE builds the plain loop.
+template <int N4, int NT>
+__device__ __forceinline__ void copy_to_lds(f32x4* __restrict__ d4, const f32x4* __restrict__ s4, int tid) {
+#ifndef PESTO_SERIAL_PROLOGUE
+    constexpr int NIT = (N4 + NT - 1) / NT, BATCH = 8;
+#pragma unroll
+    for (int j0 = 0; j0 < NIT; j0 += BATCH) {
+        f32x4 tmp[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int k = tid + (j0 + j) * NT;
+            if (j0 + j < NIT) tmp[j] = s4[k < N4 ? k : N4 - 1];      // (unconditional, and pinned below: a masked last load was sunk behind the other stores)
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+            if (j0 + j < NIT) asm volatile("" : "+v"(tmp[j]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int k = tid + (j0 + j) * NT;
+            if (j0 + j < NIT && k < N4) d4[k] = tmp[j];
+        }
+    }
+#else
+    for (int k = tid; k < N4; k += NT) d4[k] = s4[k];
+#endif
+}
 template <int NM>
 __device__ __forceinline__ void mfma16_multi(const float* __restrict__ wf, int m0, int nkg, int kgp, int lane, f16x8 xh, f16x8 xl,
                                              f32x4* acc) {
@@ -442,17 +472,14 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
     __shared__ __attribute__((aligned(16))) float wl_[NODE_LDS_FLOATS];
     __shared__ __attribute__((aligned(16))) float xch[2][8][256];     // [tile slot][q0 q1 p00 p01 p10 p11 p20 p21][lane][4]
     {   // one fill: [q0 | q1 | q2 | pp] (contiguous in the image), [U|A], G (first half of the [G|C] table), [n0 | n1 | n2]
-        auto copy = [&](int dst, const float* src, int n_floats) {
-            const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-            f32x4* d4 = reinterpret_cast<f32x4*>(wl_ + dst);
-            for (int k = threadIdx.x; k < n_floats / 4; k += NODE_WAVES * 64) d4[k] = s4[k];
-        };
-        if (do_finish) copy(NL_FIN, W + wf_.h_q0, 6144);
+#define PESTO_NODE_COPY(dst, src, n_floats) copy_to_lds<(n_floats) / 4, NODE_WAVES * 64>(reinterpret_cast<f32x4*>(wl_ + (dst)), reinterpret_cast<const f32x4*>(src), (int)threadIdx.x)
+        if (do_finish) PESTO_NODE_COPY(NL_FIN, W + wf_.h_q0, 6144);
         if (do_prep) {
-            copy(NL_UA, W + wp_.h_ua, 16384);
-            copy(NL_GC, W + wp_.h_gc, 4096);
-            copy(NL_NQ, W + wp_.h_n0, 3584);
+            PESTO_NODE_COPY(NL_UA, W + wp_.h_ua, 16384);
+            PESTO_NODE_COPY(NL_GC, W + wp_.h_gc, 4096);
+            PESTO_NODE_COPY(NL_NQ, W + wp_.h_n0, 3584);
         }
+#undef PESTO_NODE_COPY
     }
     // XCD-aware partition of tile PAIRS (same atom ranges per XCD as the edge kernel's work items)
     const int n_tiles = (N1 + 15) >> 4, n_pairs = (n_tiles + 1) >> 1, chunk = (n_pairs + 7) >> 3;
@@ -1572,8 +1599,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     }
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
         const f32x4* src = reinterpret_cast<const f32x4*>(W + (M32 ? lw.e_lds32 : F16 ? lw.e_lds16 : lw.e_lds));
-        f32x4* dst = reinterpret_cast<f32x4*>(sm.w);
-        for (int k = threadIdx.x; k < (M32 ? EDGE_LDS_FLOATS_32 : HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS) / 4; k += WPB * 64) dst[k] = src[k];
+        copy_to_lds<(M32 ? EDGE_LDS_FLOATS_32 : HY ? EDGE_LDS_FLOATS_HY : EDGE_LDS_FLOATS) / 4, WPB * 64>(reinterpret_cast<f32x4*>(sm.w), src, (int)threadIdx.x);
     }
     if constexpr (HY && !M32) {
         if (threadIdx.x < 64) {
