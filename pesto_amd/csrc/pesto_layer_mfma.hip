@@ -1644,6 +1644,306 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     // share gathered lines in the L1). The LAST iteration of an XCD's share (fewer items left than slots - in a small launch the only
     // one): the second items start behind the first items of ALL workgroups, so that the remainder is spread over the workgroups
     // instead of giving a few of them two items per wave and the rest none. Same trip count for every workgroup of the XCD.
+    if constexpr (NODEW) {
+      if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= NE) {
+        // ======== the node waves' own loop (same iteration arithmetic as the item waves' loop below; separate since round 5, so that the
+        // two kinds of waves are two register-allocation problems: the item loop's live values no longer sit under the node chain)
+        // ---- node-wave mode: the same finish + prepare arithmetic, but by four waves that do nothing else, fed through LDS queues.
+        // An edge wave stages the Z rows of its two centres of this iteration in generation (iteration & 1) of its staging rows,
+        // counts itself in XF_READY[generation] and goes straight on to its next items: no rendezvous, no weight fragments, no
+        // record stores (whose acknowledgements the next gathers of the same wave would have to wait for) on the waves that
+        // carry the edge work. Node wave r (role r: 0 = q, c + 1 = p[c]) waits for the eight edge waves, copies its part of the 16
+        // rows to registers, counts itself in XF_CONSUMED (two iterations later the edge waves overwrite the generation), runs its
+        // finish chain, posts its slice of the new tile state (exchange buffer, also two generations), then G[c] (roles 1..3), and
+        // - once all four slices are posted - Q (role 0) and the [U|A] blocks 4r..4r+3.
+        constexpr int CPW = A * SUBS;
+        const int lane = threadIdx.x & 63;
+        const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        for (int it_start = xcd * chunk; it_start < w_end; it_start += nbx * NE * SUBS) {
+            const bool tail = w_end - it_start < nbx * NE * SUBS;
+            const int sstride = tail ? nbx * NE : NE;
+            const int base = it_start + jb * NE * (tail ? 1 : SUBS);
+            const int gen = fin_iter & 1;
+            (void)sstride;
+            // weight fragments of the node waves: plain global loads, or (-DPESTO_NODEW_WAUX=<aux>, developer) buffer loads with cache-policy bits
+            // (gfx950: 1 = sc0, 2 = nt, 16 = sc1) - the 166 KB stream per 16 centres goes through the 32 KB L1 the gathers live in
+#ifdef PESTO_NODEW_WAUX
+            const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W);
+#define LDW(ptr) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(((ptr) - W) * 4), 0, PESTO_NODEW_WAUX))
+#else
+#define LDW(ptr) ld8h(ptr)
+#endif
+            // (two teams: team t takes the iterations of generation t - a tile's chain may then last two iterations)
+            const int role = (wave_u - NE) & 3;
+            const bool prep = rec_cen_out != nullptr;
+            const int tq = NTEAM == 2 ? gen : 0;          // counters / exchange buffer of this team
+#pragma unroll 1
+          for (int ntile = 0; ntile < ((NTEAM == 2 && ((wave_u - NE) >> 2) != gen) ? 0 : NWT); ++ntile) {
+            // (the lane index is re-derived per tile from an opaque copy - as invariants of the node waves' loop the weight fragments of the
+            // whole phase would be loaded once in front of it and live across it)
+            int lane_n = lane;
+            asm volatile("" : "+v"(lane_n));
+            const int fe = lane_n & 15, fg = lane_n >> 4;
+            // centre of MFMA column fe: edge wave fe / CPW (+ 16 / CPW per tile), its staged row fe % CPW (work-item arithmetic of the loop above)
+            const int cw_raw = ntile * (16 / CPW) + fe / CPW, cr = fe % CPW;
+            const int cw = NWT > 1 ? min(cw_raw, NE - 1) : cw_raw;
+            const int cwork = base + (SUBS > 1 ? cr * sstride : 0) + cw;
+            const int ci_raw = cwork * A + (SUBS > 1 ? 0 : cr);
+            const bool valid = cwork < w_end && ci_raw < N1 && cw_raw < NE;
+            const int ci = valid ? ci_raw : 0;
+            const float* zr = sm.zrows[cw][gen][cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
+            const float st_limit = state_limit_of(flags);      // conditioning trigger
+            const float* fb = W + lw.h_q0 + lane_n * 4;       // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
+            const int ntile_seq = fin_iter * NWT + ntile;   // tiles this workgroup's node waves have taken before this one
+            // exchange buffer, two generations (a wave posts its next tile while a slower wave of its team still reads this one)
+            float* xs = sm.xch + (NTEAM == 2 ? 2 * tq + ((fin_iter >> 1) & 1) : (ntile_seq & 1)) * 2048;    // [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column 16][4]
+            float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
+            f16x8 zh[2], zl[2];
+            auto rows = [&]() {                 // wait for the tile's edge waves, then this role's part of the 16 rows as hi/lo B operands
+                if (NWT > 1 && ntile == 1) lds_wait_ge<16>(&sm.xflag[XF_READY2 + gen], (NE - 8) * ((fin_iter >> 1) + 1));
+                else lds_wait_ge<16>(&sm.xflag[XF_READY + gen], (NE < 8 ? NE : 8) * ((fin_iter >> 1) + 1));
+#pragma unroll
+                for (int kgp = 0; kgp < 2; ++kgp) {
+                    f32x4 a0 = ld4(zr + 32 * kgp + 4 * fg), a1 = ld4(zr + 32 * kgp + 16 + 4 * fg);
+                    if (!valid) { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }     // unused columns: no stale LDS bits into the range guard
+                    split8(a0, a1, zh[kgp], zl[kgp]);
+                }
+                lds_signal(&sm.xflag[XF_CONSUMED + tq], lane_n == 0);
+#ifdef PESTO_NODEW_PRIO      // (developer: priority of a node wave while it computes; it polls at priority 0)
+                __builtin_amdgcn_s_setprio(PESTO_NODEW_PRIO);
+#endif
+            };
+            auto post = [&](const f32x4* v) {
+                st4(xs + ((2 * role) * 4 + fg) * 64 + fe * 4, v[0]);
+                st4(xs + ((2 * role + 1) * 4 + fg) * 64 + fe * 4, v[1]);
+                lds_signal(&sm.xflag[XF_POST + tq], lane_n == 0);
+            };
+#define PESTO_FIN_MFMA(acc, fr, xh_, xl_)                                                   \
+    {                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xh_, acc[m]);     \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xl_, acc[m]);     \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m + 1], xh_, acc[m]); \
+    }
+#ifdef PESTO_ABL_NONODE      // ablation (results wrong): the node waves only keep the queues moving - what the item waves cost by themselves
+            rows();
+            sat_probe(sat, __builtin_bit_cast(float, (int)zh[0][0]));
+            lds_signal(&sm.xflag[XF_POST + tq], lane_n == 0);
+            continue;
+#endif
+            f32x4 st[2];
+            // From here to the end of the tile the two role classes (0: q; 1..3: p[c]) are SEPARATE paths (always-inline lambdas for what they
+            // share): the weight fragments one class holds are then not live on the other's path (round 5; the node waves' loop is a register
+            // allocation of its own). Role 0 - the longest chain of a tile: qpm's three layers, its [U|A] blocks, nqm's three layers - requests
+            // nqm's first-layer fragments in front of the [U|A] products instead of behind them (-DPESTO_NODEW_NOPREFETCH: the old order);
+            // all of nqm there, or the G fragments of roles 1..3 ahead of the wait for the staged rows (-DPESTO_NODEW_PREFETCH_G), do not fit
+            // 168 registers (62 ... 133 spilled). Same MFMA order per accumulator: same bits.
+            auto finish_state = [&]() __attribute__((always_inline)) {
+                sat_probe(sat, st[0][0]);          // (unused columns were fed zeros and the sink row's finite state)
+                if (valid) mag_flush_at(st[0], st[1], st_limit, flags, ci);
+                if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
+                if (valid) {
+                    float* dst = role == 0 ? q_out + (size_t)ci * S : p_out + (size_t)ci * 96 + (role - 1) * 32;
+                    st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]);
+                }
+            };
+            // ---- the NEXT layer's records of these 16 centres (k_node16's prepare half, same arithmetic: model_operations.py:103-119)
+            const int ob = 4 * role;              // the [U | A] blocks of this wave: 4 role .. 4 role + 3
+            f16x8 ua[2][4][2];                    // [kgp][block][hi|lo]
+            f32x4 ub[4];
+            auto load_ua = [&]() __attribute__((always_inline)) {
+                const float* Lua = W + lwp.h_ua + lane_n * 4;          // [m 16][kgp 2][hi|lo][256]
+#pragma unroll
+                for (int kgp = 0; kgp < 2; ++kgp)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float* fr = Lua + (size_t)(((ob + j) * 2 + kgp) * 2) * 256;
+                        ua[kgp][j][0] = LDW(fr); ua[kgp][j][1] = LDW(fr + 256);
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ub[j] = ob < 8 ? ld4(W + lwp.n_b1s + 16 * (ob + j) + 4 * fg) : f32x4{0, 0, 0, 0};
+            };
+            f16x8 xnh[2], xnl[2];
+            auto tile_inputs = [&]() __attribute__((always_inline)) {      // once all four slices are posted: [q | ||p||] of the tile as f16 hi/lo B operands (k-group 0 = q, 1 = ||p||)
+                lds_wait_ge(&sm.xflag[XF_POST + tq], NTEAM == 2 ? 4 * (fin_iter >> 1) + 4 : 4 * ntile_seq + 4);
+                f32x4 q[2], pn[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f32x4 p3[3];
+                    q[m] = ld4(xs + (m * 4 + fg) * 64 + fe * 4);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) p3[c] = ld4(xs + ((2 + 2 * c + m) * 4 + fg) * 64 + fe * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pn[m][r] = norm3_fast(p3[0][r], p3[1][r], p3[2][r]);
+                }
+                split8(q[0], q[1], xnh[0], xnl[0]);
+                split8(pn[0], pn[1], xnh[1], xnl[1]);
+            };
+            auto ua_products = [&]() __attribute__((always_inline)) {
+                f32x4 a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = ub[j];
+#pragma unroll
+                for (int kgp = 0; kgp < 2; ++kgp) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnh[kgp], a[j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnl[kgp], a[j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][1], xnh[kgp], a[j]);
+                }
+                sat_probe(sat, a[0][0]);
+                if (valid) {
+                    float* nb = rec_nb_out + (size_t)ABL_ST(ci) * REC_A;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (ob < 8) st4_finite(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
+                        else st4(nb + (ob + j - 8) * 16 + 4 * fg, a[j]);                   // A_j[16 fb + 4g + r]
+                    }
+                }
+            };
+            if (role == 0) {   // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147, :151)
+                f16x8 w0[2][4], w1[4], w2[4];            // [kgp][(m, hi|lo)], [(m, hi|lo)]
+                f32x4 h[2], b1v[2], b2v[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) { w0[kgp][2 * m] = LDW(fb + ((m * 2 + kgp) * 2) * 256); w0[kgp][2 * m + 1] = LDW(fb + ((m * 2 + kgp) * 2 + 1) * 256); }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) { w1[f] = LDW(fb + (8 + f) * 256); w2[f] = LDW(fb + (12 + f) * 256); }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    h[m] = ld4(W + lw.n_bq0 + 16 * m + 4 * fg); b1v[m] = ld4(W + lw.n_bq1 + 16 * m + 4 * fg); b2v[m] = ld4(W + lw.n_bq2 + 16 * m + 4 * fg);
+                    st[m] = ld4(q_state + (size_t)ci * S + 16 * m + 4 * fg);
+                }
+                rows();
+                PESTO_FIN_MFMA(h, w0[0], zh[0], zl[0])
+                PESTO_FIN_MFMA(h, w0[1], zh[1], zl[1])
+                sat_probe(sat, h[0][0]);
+                f16x8 xh, xl;
+                split8(elu4(h[0]), elu4(h[1]), xh, xl);
+                PESTO_FIN_MFMA(b1v, w1, xh, xl)
+                sat_probe(sat, b1v[0][0]);
+                split8(elu4(b1v[0]), elu4(b1v[1]), xh, xl);
+                PESTO_FIN_MFMA(b2v, w2, xh, xl)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) st[m] += b2v[m];
+                finish_state();
+                if (prep) {
+                    post(st);
+                    load_ua();               // on their way while the other slices are being posted (requested earlier - behind qpm's first layer - they spill 102 registers)
+                    // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12 (:119): fragments n0 [m 2][kgp 2] | n1 [m 2] | n2 [1], (hi, lo) pairs of 256 floats
+                    const float* nq = W + lwp.h_n0 + lane_n * 4;
+                    f16x8 n0[2][4], n1[4], n2[2];
+                    f32x4 hq[2], tq2[2], qq[1];
+                    auto load_nq0 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int kgp = 0; kgp < 2; ++kgp) { n0[kgp][2 * m] = LDW(nq + ((m * 2 + kgp) * 2) * 256); n0[kgp][2 * m + 1] = LDW(nq + ((m * 2 + kgp) * 2 + 1) * 256); }
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) hq[m] = ld4(W + lwp.n_bn0 + 16 * m + 4 * fg);
+                    };
+                    tile_inputs();
+#ifndef PESTO_NODEW_NOPREFETCH
+                    load_nq0();              // nqm's first layer: requested in front of the [U|A] products (all of nqm here: 168 registers do not hold it)
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    ua_products();
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef PESTO_NODEW_NOPREFETCH
+                    load_nq0();
+#endif
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) n1[f] = LDW(nq + (8 + f) * 256);
+                    n2[0] = LDW(nq + 12 * 256); n2[1] = LDW(nq + 13 * 256);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) tq2[m] = ld4(W + lwp.n_bn1 + 16 * m + 4 * fg);
+                    qq[0] = ld4(W + lwp.n_bn2 + 4 * fg);
+                    PESTO_FIN_MFMA(hq, n0[0], xnh[0], xnl[0])
+                    PESTO_FIN_MFMA(hq, n0[1], xnh[1], xnl[1])
+                    sat_probe(sat, hq[0][0]);
+                    split8(elu4(hq[0]), elu4(hq[1]), xh, xl);
+                    PESTO_FIN_MFMA(tq2, n1, xh, xl)
+                    sat_probe(sat, tq2[0][0]);
+                    split8(elu4(tq2[0]), elu4(tq2[1]), xh, xl);
+                    qq[0] = MFMA16(n2[0], xh, qq[0]); qq[0] = MFMA16(n2[0], xl, qq[0]); qq[0] = MFMA16(n2[1], xh, qq[0]);
+                    sat_probe(sat, qq[0][0]);
+                    if (valid) st4(cen + 512 + 4 * fg, qq[0]);
+                }
+            } else {           // ppm: 64 -> 32, no bias, xyz component role - 1             (:148, :152)
+                f16x8 wp[2][4];
+                f16x8 gw[8][2];          // G[c] fragments, both halves
+                const float* Lgc = W + lwp.h_gc + lane_n * 4;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int kgp = 0; kgp < 2; ++kgp) { wp[kgp][2 * m] = LDW(fb + 4096 + ((m * 2 + kgp) * 2) * 256); wp[kgp][2 * m + 1] = LDW(fb + 4096 + ((m * 2 + kgp) * 2 + 1) * 256); }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) st[m] = ld4(p_state + (size_t)ci * 96 + (role - 1) * 32 + 16 * m + 4 * fg);
+#ifdef PESTO_NODEW_PREFETCH_G      // (developer: the G fragments requested while the wave waits for the staged rows - 62 ... 99 registers spilled)
+                if (prep) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { gw[j][0] = LDW(Lgc + (j * 2) * 256); gw[j][1] = LDW(Lgc + (j * 2 + 1) * 256); }
+                }
+#endif
+                rows();
+                f32x4 h[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+                PESTO_FIN_MFMA(h, wp[0], zh[0], zl[0])
+                PESTO_FIN_MFMA(h, wp[1], zh[1], zl[1])
+#pragma unroll
+                for (int m = 0; m < 2; ++m) st[m] += h[m];
+                finish_state();
+                if (prep) {
+                    post(st);
+                    {   // G[c] blocks 0..7 straight from the own slice p[c], c = role - 1
+                        f16x8 ph, pl;
+                        split8(st[0], st[1], ph, pl);
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            f32x4 a[4];
+#ifndef PESTO_NODEW_PREFETCH_G
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { gw[4 * half + j][0] = LDW(Lgc + ((4 * half + j) * 2) * 256); gw[4 * half + j][1] = LDW(Lgc + ((4 * half + j) * 2 + 1) * 256); }
+#endif
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) a[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[4 * half + j][0], ph, a[j]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[4 * half + j][0], pl, a[j]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[4 * half + j][1], ph, a[j]);
+                            sat_probe(sat, a[0][0]);
+                            if (valid) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) st4_finite(cen + (4 * half + j) * 64 + (role - 1) * 16 + 4 * fg, a[j]);
+                            }
+#ifdef PESTO_NODEW_PREFETCH_G
+                            // behind the first half of G: the second half's products and the wait for the slices cover the round trip
+                            if (half == 0) { __builtin_amdgcn_sched_barrier(0); load_ua(); __builtin_amdgcn_sched_barrier(0); }
+#endif
+                        }
+                    }
+#ifndef PESTO_NODEW_PREFETCH_G
+                    load_ua();
+#endif
+                    tile_inputs();
+                    ua_products();
+                }
+            }
+#undef PESTO_FIN_MFMA
+            if (valid) sat_flush_at(sat, flags, ci);      // (the probes of a node wave are MFMA column fe = centre ci)
+            sat = 0.0f;
+#ifdef PESTO_NODEW_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+          }      // ntile
+#undef LDW
+            ++fin_iter;
+        }
+        return;      // (every probe of a node wave has been flushed with its tile)
+      }
+    }
     for (int it_start = xcd * chunk; it_start < w_end; it_start += nbx * NE * SUBS) {
       // the lane-derived values of the work loop (indices, LDS addresses, masks) are re-derived per iteration from an opaque copy of the
       // thread index: as loop invariants they would stay in registers across the finish / prepare phase below, which needs them for
@@ -3017,257 +3317,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         ++fin_iter;
       }
       if (NODEW) {
-        // ---- node-wave mode: the same finish + prepare arithmetic, but by four waves that do nothing else, fed through LDS queues.
-        // An edge wave stages the Z rows of its two centres of this iteration in generation (iteration & 1) of its staging rows,
-        // counts itself in XF_READY[generation] and goes straight on to its next items: no rendezvous, no weight fragments, no
-        // record stores (whose acknowledgements the next gathers of the same wave would have to wait for) on the waves that
-        // carry the edge work. Node wave r (role r: 0 = q, c + 1 = p[c]) waits for the eight edge waves, copies its part of the 16
-        // rows to registers, counts itself in XF_CONSUMED (two iterations later the edge waves overwrite the generation), runs its
-        // finish chain, posts its slice of the new tile state (exchange buffer, also two generations), then G[c] (roles 1..3), and
-        // - once all four slices are posted - Q (role 0) and the [U|A] blocks 4r..4r+3.
-        constexpr int CPW = A * SUBS;
+        // ---- node-wave mode, the item waves' side: the Z rows of this iteration's centres are staged in generation (iteration & 1) of the
+        // wave's staging rows; the wave counts itself in XF_READY[generation] and goes straight on to its next items - no rendezvous, no
+        // weight fragments, no record stores (whose acknowledgements the next gathers of the same wave would have to wait for). The node
+        // waves run a loop of their own in front of this one (round 5: one register allocation per loop).
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const int gen = fin_iter & 1;
-        if (wave_u < NE) {
-            // (twelve item waves: the waves of the second, half-filled tile count in a counter of their own - the node waves start on the
-            // first tile as soon as ITS eight waves have staged)
-            lds_signal(&sm.xflag[((NWT > 1 && wave_u >= 8) ? XF_READY2 : XF_READY) + gen], lane == 0);
-        } else {
-            // weight fragments of the node waves: plain global loads, or (-DPESTO_NODEW_WAUX=<aux>, developer) buffer loads with cache-policy bits
-            // (gfx950: 1 = sc0, 2 = nt, 16 = sc1) - the 166 KB stream per 16 centres goes through the 32 KB L1 the gathers live in
-#ifdef PESTO_NODEW_WAUX
-            const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W);
-#define LDW(ptr) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)(((ptr) - W) * 4), 0, PESTO_NODEW_WAUX))
-#else
-#define LDW(ptr) ld8h(ptr)
-#endif
-            // (two teams: team t takes the iterations of generation t - a tile's chain may then last two iterations)
-            const int role = (wave_u - NE) & 3;
-            const bool prep = rec_cen_out != nullptr;
-            const int tq = NTEAM == 2 ? gen : 0;          // counters / exchange buffer of this team
-#pragma unroll 1
-          for (int ntile = 0; ntile < ((NTEAM == 2 && ((wave_u - NE) >> 2) != gen) ? 0 : NWT); ++ntile) {
-            // (several tiles per iteration: the lane index is re-derived per tile from an opaque copy - as invariants of this loop the weight
-            // fragments of the whole phase would be loaded once in front of it and live across it)
-            int lane_n = lane;
-#ifdef PESTO_HOIST_NW
-            asm volatile("" : "+v"(lane_n));
-#else
-            if (NWT > 1) asm volatile("" : "+v"(lane_n));
-#endif
-            const int fe = lane_n & 15, fg = lane_n >> 4;
-            // centre of MFMA column fe: edge wave fe / CPW (+ 16 / CPW per tile), its staged row fe % CPW (work-item arithmetic of the loop above)
-            const int cw_raw = ntile * (16 / CPW) + fe / CPW, cr = fe % CPW;
-            const int cw = NWT > 1 ? min(cw_raw, NE - 1) : cw_raw;
-            const int cwork = base + (SUBS > 1 ? cr * sstride : 0) + cw;
-            const int ci_raw = cwork * A + (SUBS > 1 ? 0 : cr);
-            const bool valid = cwork < w_end && ci_raw < N1 && cw_raw < NE;
-            const int ci = valid ? ci_raw : 0;
-            const float* zr = sm.zrows[cw][gen][cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
-            const float st_limit = state_limit_of(flags);      // conditioning trigger
-            const float* fb = W + lw.h_q0 + lane_n * 4;       // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
-            const int ntile_seq = fin_iter * NWT + ntile;   // tiles this workgroup's node waves have taken before this one
-            // exchange buffer, two generations (a wave posts its next tile while a slower wave of its team still reads this one)
-            float* xs = sm.xch + (NTEAM == 2 ? 2 * tq + ((fin_iter >> 1) & 1) : (ntile_seq & 1)) * 2048;    // [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column 16][4]
-            float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
-            f16x8 zh[2], zl[2];
-            auto rows = [&]() {                 // wait for the tile's edge waves, then this role's part of the 16 rows as hi/lo B operands
-                if (NWT > 1 && ntile == 1) lds_wait_ge<16>(&sm.xflag[XF_READY2 + gen], (NE - 8) * ((fin_iter >> 1) + 1));
-                else lds_wait_ge<16>(&sm.xflag[XF_READY + gen], (NE < 8 ? NE : 8) * ((fin_iter >> 1) + 1));
-#pragma unroll
-                for (int kgp = 0; kgp < 2; ++kgp) {
-                    f32x4 a0 = ld4(zr + 32 * kgp + 4 * fg), a1 = ld4(zr + 32 * kgp + 16 + 4 * fg);
-                    if (!valid) { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }     // unused columns: no stale LDS bits into the range guard
-                    split8(a0, a1, zh[kgp], zl[kgp]);
-                }
-                lds_signal(&sm.xflag[XF_CONSUMED + tq], lane_n == 0);
-#ifdef PESTO_NODEW_PRIO      // (developer: priority of a node wave while it computes; it polls at priority 0)
-                __builtin_amdgcn_s_setprio(PESTO_NODEW_PRIO);
-#endif
-            };
-            auto post = [&](const f32x4* v) {
-                st4(xs + ((2 * role) * 4 + fg) * 64 + fe * 4, v[0]);
-                st4(xs + ((2 * role + 1) * 4 + fg) * 64 + fe * 4, v[1]);
-                lds_signal(&sm.xflag[XF_POST + tq], lane_n == 0);
-            };
-#define PESTO_FIN_MFMA(acc, fr, xh_, xl_)                                                   \
-    {                                                                                        \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xh_, acc[m]);     \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xl_, acc[m]);     \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m + 1], xh_, acc[m]); \
-    }
-#ifdef PESTO_ABL_NONODE      // ablation (results wrong): the node waves only keep the queues moving - what the item waves cost by themselves
-            rows();
-            sat_probe(sat, __builtin_bit_cast(float, (int)zh[0][0]));
-            lds_signal(&sm.xflag[XF_POST + tq], lane_n == 0);
-            continue;
-#endif
-            f32x4 st[2];
-            if (role == 0) {   // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147, :151)
-                f16x8 w0[2][4], w1[4], w2[4];            // [kgp][(m, hi|lo)], [(m, hi|lo)]
-                f32x4 h[2], b1v[2], b2v[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp) { w0[kgp][2 * m] = LDW(fb + ((m * 2 + kgp) * 2) * 256); w0[kgp][2 * m + 1] = LDW(fb + ((m * 2 + kgp) * 2 + 1) * 256); }
-#pragma unroll
-                for (int f = 0; f < 4; ++f) { w1[f] = LDW(fb + (8 + f) * 256); w2[f] = LDW(fb + (12 + f) * 256); }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    h[m] = ld4(W + lw.n_bq0 + 16 * m + 4 * fg); b1v[m] = ld4(W + lw.n_bq1 + 16 * m + 4 * fg); b2v[m] = ld4(W + lw.n_bq2 + 16 * m + 4 * fg);
-                    st[m] = ld4(q_state + (size_t)ci * S + 16 * m + 4 * fg);
-                }
-                rows();
-                PESTO_FIN_MFMA(h, w0[0], zh[0], zl[0])
-                PESTO_FIN_MFMA(h, w0[1], zh[1], zl[1])
-                sat_probe(sat, h[0][0]);
-                f16x8 xh, xl;
-                split8(elu4(h[0]), elu4(h[1]), xh, xl);
-                PESTO_FIN_MFMA(b1v, w1, xh, xl)
-                sat_probe(sat, b1v[0][0]);
-                split8(elu4(b1v[0]), elu4(b1v[1]), xh, xl);
-                PESTO_FIN_MFMA(b2v, w2, xh, xl)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) st[m] += b2v[m];
-            } else {           // ppm: 64 -> 32, no bias, xyz component role - 1             (:148, :152)
-                f16x8 wp[2][4];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp) { wp[kgp][2 * m] = LDW(fb + 4096 + ((m * 2 + kgp) * 2) * 256); wp[kgp][2 * m + 1] = LDW(fb + 4096 + ((m * 2 + kgp) * 2 + 1) * 256); }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) st[m] = ld4(p_state + (size_t)ci * 96 + (role - 1) * 32 + 16 * m + 4 * fg);
-                rows();
-                f32x4 h[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-                PESTO_FIN_MFMA(h, wp[0], zh[0], zl[0])
-                PESTO_FIN_MFMA(h, wp[1], zh[1], zl[1])
-#pragma unroll
-                for (int m = 0; m < 2; ++m) st[m] += h[m];
-            }
-            sat_probe(sat, st[0][0]);          // (unused columns were fed zeros and the sink row's finite state)
-            if (valid) mag_flush_at(st[0], st[1], st_limit, flags, ci);
-            if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
-            if (valid) {
-                float* dst = role == 0 ? q_out + (size_t)ci * S : p_out + (size_t)ci * 96 + (role - 1) * 32;
-                st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]);
-            }
-            if (prep) {
-                // ---- the NEXT layer's records of these 16 centres (k_node16's prepare half, same arithmetic: model_operations.py:103-119)
-                post(st);
-                if (role != 0) {   // G[c] blocks 0..7 straight from the own slice p[c], c = role - 1
-                    f16x8 ph, pl;
-                    split8(st[0], st[1], ph, pl);
-                    const float* Lgc = W + lwp.h_gc + lane_n * 4;
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        f16x8 gw[4][2];
-                        f32x4 a[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { gw[j][0] = LDW(Lgc + ((4 * half + j) * 2) * 256); gw[j][1] = LDW(Lgc + ((4 * half + j) * 2 + 1) * 256); a[j] = f32x4{0, 0, 0, 0}; }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[j][0], ph, a[j]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[j][0], pl, a[j]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[j][1], ph, a[j]);
-                        sat_probe(sat, a[0][0]);
-                        if (valid) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) st4_finite(cen + (4 * half + j) * 64 + (role - 1) * 16 + 4 * fg, a[j]);
-                        }
-                    }
-                }
-                // the [U | A] fragments of this wave (blocks 4 role .. 4 role + 3): on their way while the other slices are being posted
-                const int ob = 4 * role;
-                f16x8 ua[2][4][2];                    // [kgp][block][hi|lo]
-                f32x4 ub[4];
-                {
-                    const float* Lua = W + lwp.h_ua + lane_n * 4;          // [m 16][kgp 2][hi|lo][256]
-#pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float* fr = Lua + (size_t)(((ob + j) * 2 + kgp) * 2) * 256;
-                            ua[kgp][j][0] = LDW(fr); ua[kgp][j][1] = LDW(fr + 256);
-                        }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ub[j] = ob < 8 ? ld4(W + lwp.n_b1s + 16 * (ob + j) + 4 * fg) : f32x4{0, 0, 0, 0};
-                }
-                lds_wait_ge(&sm.xflag[XF_POST + tq], NTEAM == 2 ? 4 * (fin_iter >> 1) + 4 : 4 * ntile_seq + 4);
-                f16x8 xnh[2], xnl[2];
-                {   // [q | ||p||] of the tile as f16 hi/lo B operands (k-group 0 = q, 1 = ||p||)
-                    f32x4 q[2], pn[2];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        f32x4 p3[3];
-                        q[m] = ld4(xs + (m * 4 + fg) * 64 + fe * 4);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) p3[c] = ld4(xs + ((2 + 2 * c + m) * 4 + fg) * 64 + fe * 4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) pn[m][r] = norm3_fast(p3[0][r], p3[1][r], p3[2][r]);
-                    }
-                    split8(q[0], q[1], xnh[0], xnl[0]);
-                    split8(pn[0], pn[1], xnh[1], xnl[1]);
-                }
-                {
-                    f32x4 a[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] = ub[j];
-#pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnh[kgp], a[j]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnl[kgp], a[j]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][1], xnh[kgp], a[j]);
-                    }
-                    sat_probe(sat, a[0][0]);
-                    if (valid) {
-                        float* nb = rec_nb_out + (size_t)ABL_ST(ci) * REC_A;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (ob < 8) st4_finite(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
-                            else st4(nb + (ob + j - 8) * 16 + 4 * fg, a[j]);                   // A_j[16 fb + 4g + r]
-                        }
-                    }
-                }
-                if (role == 0) {   // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12                        (:119)
-                    const float* nq = W + lwp.h_n0 + lane_n * 4;     // fragments n0 [m 2][kgp 2] | n1 [m 2] | n2 [1], (hi, lo) pairs of 256 floats
-                    f16x8 n0[2][4], n1[4], n2[2];
-                    f32x4 hq[2], tq[2], qq[1];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int kgp = 0; kgp < 2; ++kgp) { n0[kgp][2 * m] = LDW(nq + ((m * 2 + kgp) * 2) * 256); n0[kgp][2 * m + 1] = LDW(nq + ((m * 2 + kgp) * 2 + 1) * 256); }
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) n1[f] = LDW(nq + (8 + f) * 256);
-                    n2[0] = LDW(nq + 12 * 256); n2[1] = LDW(nq + 13 * 256);
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) { hq[m] = ld4(W + lwp.n_bn0 + 16 * m + 4 * fg); tq[m] = ld4(W + lwp.n_bn1 + 16 * m + 4 * fg); }
-                    qq[0] = ld4(W + lwp.n_bn2 + 4 * fg);
-                    f16x8 xh, xl;
-                    PESTO_FIN_MFMA(hq, n0[0], xnh[0], xnl[0])
-                    PESTO_FIN_MFMA(hq, n0[1], xnh[1], xnl[1])
-                    sat_probe(sat, hq[0][0]);
-                    split8(elu4(hq[0]), elu4(hq[1]), xh, xl);
-                    PESTO_FIN_MFMA(tq, n1, xh, xl)
-                    sat_probe(sat, tq[0][0]);
-                    split8(elu4(tq[0]), elu4(tq[1]), xh, xl);
-                    qq[0] = MFMA16(n2[0], xh, qq[0]); qq[0] = MFMA16(n2[0], xl, qq[0]); qq[0] = MFMA16(n2[1], xh, qq[0]);
-                    sat_probe(sat, qq[0][0]);
-                    if (valid) st4(cen + 512 + 4 * fg, qq[0]);
-                }
-            }
-#undef PESTO_FIN_MFMA
-            if (valid) sat_flush_at(sat, flags, ci);      // (the probes of a node wave are MFMA column fe = centre ci)
-            sat = 0.0f;
-#ifdef PESTO_NODEW_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-          }      // ntile
-#undef LDW
-        }
+        // (twelve item waves: the waves of the second, half-filled tile count in a counter of their own - the node waves start on the
+        // first tile as soon as ITS eight waves have staged)
+        lds_signal(&sm.xflag[((NWT > 1 && wave_u >= 8) ? XF_READY2 : XF_READY) + gen], lane == 0);
         ++fin_iter;
       }
     }
