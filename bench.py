@@ -123,7 +123,7 @@ def load_weights(config):
 def source_hash():
     """sha256 over the kernel sources: stamps the PMC-derived traffic file so that a stale one is detectable."""
     h = hashlib.sha256()
-    for f in ("pesto_layer_mfma.hip", "pesto_kernels.hip", "pesto_api.hip", "pesto_schema.cpp", "pesto_schema.h", "pesto_kernels.h"):
+    for f in ("pesto_layer_mfma.hip", "pesto_fin_rendezvous.inc", "pesto_kernels.hip", "pesto_api.hip", "pesto_schema.cpp", "pesto_schema.h", "pesto_kernels.h"):
         h.update(open(os.path.join(ROOT, "pesto_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["pesto_schema.cpp", "pesto_kernels.hip", "pesto_layer_mfma.hip", "pesto_api.hip"]
-HEADERS = ["pesto_schema.h", "pesto_kernels.h", os.path.join("..", "..", "include", "pesto_hip.h")]
+HEADERS = ["pesto_schema.h", "pesto_kernels.h", "pesto_fin_rendezvous.inc", os.path.join("..", "..", "include", "pesto_hip.h")]
 OUT = os.path.join(HERE, "libpesto_hip.so")
 # host-only structure I/O library (include/pesto_io.h): plain C++, no HIP runtime, safe in forked data-loader workers
 IO_SOURCE = "pesto_io.cpp"

@@ -1569,6 +1569,17 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                   "node waves: four of them (16 or 24 centres per iteration), or two teams of four that take the iterations in turn");
     constexpr int NTEAM = (FIN && NE < WPB) ? (WPB - NE) / 4 : 1;
     constexpr int NWT = NODEW ? (NE * A * SUBS + 15) / 16 : 1;      // 16-centre tiles of an iteration (node-wave mode)
+    // TAILR (round 5, measured and NOT shipped; -DPESTO_TAILR builds it): the LAST iteration's tile of a node-wave workgroup finished by its
+    // eight ITEM waves behind a rendezvous - the finish / prepare phase of the eight-wave rendezvous kernels (fragments requested in front
+    // of the barrier, four finishing + four [U|A] waves) instead of the four node waves' chain that every node-wave launch ends with while
+    // its item waves have already left. Same bits (49 parity tests incl. the bitwise mode equalities) - and no gain: four runs each on
+    // one box, nn = 8 / 16 / 32 55.8 / 85.2 / 143.9 -> 55.8 / 84.4 / 142.7 us per launch, the step 1,829 -> 1,820 structures/s
+    // (profiles/r05_node_loop_ab.txt): with the SIMDs to themselves the node waves' last chain is short, and the rendezvous waits for them to end.
+#ifdef PESTO_TAILR
+    constexpr bool TAILR = NODEW && NE == 8 && WPB - NE == 4 && NE * A * SUBS == 16;
+#else
+    constexpr bool TAILR = false;
+#endif
     constexpr int WROWS = (NODEW && (NE > 8 || WPB - NE == 8)) ? 16 * TI : 64;          // rows of the per-wave scratch (sixteen-wave workgroups: LDS)
     static_assert(!M32 || (HY && NE == WPB && WPB == 8 && NN >= 16 && TI % 2 == 0), "M32: eight-wave workgroups, whole 32-edge tiles");
     __shared__ EdgeSmem<WPB, HY, FIN, NE, M32, WROWS> sm;
@@ -1660,6 +1671,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         const int lane = threadIdx.x & 63;
         const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         for (int it_start = xcd * chunk; it_start < w_end; it_start += nbx * NE * SUBS) {
+            if (TAILR && it_start + nbx * NE * SUBS >= w_end) break;      // the last iteration's tile: the item waves' (behind their loop)
             const bool tail = w_end - it_start < nbx * NE * SUBS;
             const int sstride = tail ? nbx * NE : NE;
             const int base = it_start + jb * NE * (tail ? 1 : SUBS);
@@ -1944,7 +1956,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         return;      // (every probe of a node wave has been flushed with its tile)
       }
     }
+    int last_it = 0;      // (TAILR: start of the last iteration)
     for (int it_start = xcd * chunk; it_start < w_end; it_start += nbx * NE * SUBS) {
+      last_it = it_start;
       // the lane-derived values of the work loop (indices, LDS addresses, masks) are re-derived per iteration from an opaque copy of the
       // thread index: as loop invariants they would stay in registers across the finish / prepare phase below, which needs them for
       // weight fragments (forty registers; the fragments of that phase otherwise spill in front of its rendezvous)
@@ -3025,295 +3039,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
       }   // work item
       }   // sub
       if (FIN && !NODEW) {
-        // ---- finish phase. Four waves per 16 staged centres; three steps so that the other waves wait as little as possible:
-        //   (1) before the barrier: this wave's weight fragments -> registers (one L2 round trip, overlapped with the stragglers);
-        //   (2) between two barriers: the staged Z rows -> registers (as f16 hi/lo B operands), old state loads issued;
-        //   (3) behind the second barrier (the LDS rows are free again): the MFMA chains and the state update.
-        // ---- prepare phase (rec_cen_out != null): the NEXT layer's records of these centres from the state just computed, i.e. the
-        // prepare half of k_node16 with the same arithmetic: [U|A] = W [q | ||p||] (+ b1), G[c] = Wg p[c], Q = nqm([q | ||p||])
-        // (model_operations.py:103-119). The finishing roles post their slice of the new tile state (q, p[0], p[1], p[2]) in LDS;
-        //   role c + 1: G[c] straight from its own slice (no waiting);
-        //   role 0    : Q, after the three p slices have been posted;
-        //   the four waves without a finish role: [U|A] blocks 4j..4j+3 of every tile, after all four slices have been posted.
-        // Every weight fragment of the phase is in registers BEFORE the rendezvous (a load issued behind it queues up after the
-        // gathers of the waves that are already in their next work item); the posts are counted in LDS (xflag), the waiting
-        // waves poll - all of them are resident waves of this workgroup.
-        constexpr int CPW = A * SUBS;           // staged centres per wave (1 or 2)
-        constexpr int NB = WPB * CPW, NTILE = (NB + 15) / 16;
-        static_assert(!FIN || NODEW || WPB == 4 * NTILE + 4, "four finishing waves per tile + four waves for the [U|A] blocks");
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // uniform for the compiler too: scalar branches around the role code
-        const bool prep = rec_cen_out != nullptr;
-        PHASE_INIT();
-        // lane index re-materialised behind an opaque barrier: otherwise the per-lane addresses of this phase (and the weight loads
-        // themselves) are hoisted out of the work loop as loop invariants and spilled - the main loop runs at the 168-VGPR limit
-        int lane_f = lane;
-        asm volatile("" : "+v"(lane_f));
-        const int fe = lane_f & 15, fg = lane_f >> 4;
-        // the centre of MFMA column fe of a tile follows from the work-item arithmetic, no LDS needed
-        auto centre_of = [&](int tile, int col, int& cw, int& cr, int& ci, bool& valid) {
-            const int cslot = 16 * tile + col;  // centre slot: wave cslot / CPW, staged row cslot % CPW
-            const bool cv = cslot < NB;
-            cw = cv ? cslot / CPW : 0; cr = cv ? cslot % CPW : 0;
-            const int cwork = base + (SUBS > 1 ? cr * sstride : 0) + cw;
-            const int ci_raw = cwork * A + (SUBS > 1 ? 0 : cr);
-            valid = cv && cwork < w_end && ci_raw < N1;
-            ci = valid ? ci_raw : 0;
-        };
-        auto ncol_of = [&](int tile) { return (tile == NTILE - 1 && (NB & 15) != 0) ? (NB & 15) : 16; };    // centres of a tile (compact rows)
-        auto post = [&](int tile, int blk, const f32x4* v) {      // this role's slice of the new tile state -> exchange buffer, counted
-            const int ncol = ncol_of(tile);
-            float* xs = sm.xch + tile * 2048;
-            if (fe < ncol) {
-                st4(xs + ((2 * blk) * 4 + fg) * ncol * 4 + fe * 4, v[0]);
-                st4(xs + ((2 * blk + 1) * 4 + fg) * ncol * 4 + fe * 4, v[1]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (LDS executes a wave's operations in order; this is for the compiler)
-            if (lane_f == 0) __hip_atomic_fetch_add(&sm.xflag[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        auto wait_posts = [&](int tile) {
-            const int target = 4 * fin_iter + 4;
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm.xflag[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-                __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-        };
-        // [q | ||p||] of a posted tile as f16 hi/lo B operands (k-group 0 = q, 1 = ||p||)
-        auto node_input = [&](int tile, f16x8* xnh, f16x8* xnl) {
-            const int ncol = ncol_of(tile);
-            const float* xs = sm.xch + tile * 2048;
-            const bool xv = fe < ncol;
-            f32x4 q[2], pn[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                f32x4 p3[3];
-                q[m] = ld4(xs + (m * 4 + fg) * ncol * 4 + fe * 4);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) p3[c] = ld4(xs + ((2 + 2 * c + m) * 4 + fg) * ncol * 4 + fe * 4);
-                if (!xv) { q[m] = f32x4{0, 0, 0, 0}; p3[0] = q[m]; p3[1] = q[m]; p3[2] = q[m]; }    // (columns past the tile: not stored)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pn[m][r] = norm3_fast(p3[0][r], p3[1][r], p3[2][r]);
-            }
-            split8(q[0], q[1], xnh[0], xnl[0]);
-            split8(pn[0], pn[1], xnh[1], xnl[1]);
-        };
-        // acc[m] += W[m-block] x (K = 32 k-group): three products of the hi/lo split; fragments fr[(m, hi|lo)]
-#define PESTO_FIN_MFMA(acc, fr, xh_, xl_)                                                   \
-    {                                                                                        \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xh_, acc[m]);     \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m], xl_, acc[m]);     \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = MFMA16((fr)[2 * m + 1], xh_, acc[m]); \
-    }
-        if (wave_u < 4 * NTILE) {
-            const int tile = wave_u >> 2, role = wave_u & 3;
-            // Every global load of the finish - weight fragments, biases, the OLD state of this column's centre - is issued BEFORE the
-            // rendezvous: behind it a load queues up after the gathers the other waves have issued meanwhile (microseconds under load
-            // per dependent round trip).
-            int cw, cr, ci; bool valid;
-            centre_of(tile, fe, cw, cr, ci, valid);
-            const float st_limit = state_limit_of(flags);      // conditioning trigger (with the other loads in front of the rendezvous)
-            const float* zr = sm.zrows[cw][0][cr] + (role == 0 ? 0 : 64 + (role - 1) * 64);
-            const float* fb = W + lw.h_q0 + lane_f * 4;     // fragments q0 | q1 | q2 | pp contiguous in the image, 256 floats each
-            f16x8 zh[2], zl[2];
-            auto rows = [&]() {                 // the staged Z rows of this role as f16 hi/lo B operands (K = 64: two k-groups)
-#pragma unroll
-                for (int kgp = 0; kgp < 2; ++kgp) {
-                    f32x4 a0 = ld4(zr + 32 * kgp + 4 * fg), a1 = ld4(zr + 32 * kgp + 16 + 4 * fg);
-                    if (!valid) { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }     // unused columns: no stale LDS bits into the range guard
-                    split8(a0, a1, zh[kgp], zl[kgp]);
-                }
-            };
-            float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
-            f32x4 st[2], h[2];
-            if (role == 0) {   // qpm: 64 -> 32 -> 32 -> 32 with ELU between            (model_operations.py:147, :151)
-                f16x8 w0[2][4], w1[4], w2[4];            // [kgp][(m, hi|lo)], [(m, hi|lo)]
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp) { w0[kgp][2 * m] = ld8h(fb + ((m * 2 + kgp) * 2) * 256); w0[kgp][2 * m + 1] = ld8h(fb + ((m * 2 + kgp) * 2 + 1) * 256); }
-#pragma unroll
-                for (int f = 0; f < 4; ++f) { w1[f] = ld8h(fb + (8 + f) * 256); w2[f] = ld8h(fb + (12 + f) * 256); }
-                f32x4 b1v[2], b2v[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    h[m] = ld4(W + lw.n_bq0 + 16 * m + 4 * fg); b1v[m] = ld4(W + lw.n_bq1 + 16 * m + 4 * fg); b2v[m] = ld4(W + lw.n_bq2 + 16 * m + 4 * fg);
-                    st[m] = ld4(q_state + (size_t)ci * S + 16 * m + 4 * fg);
-                }
-                PHASE_MARK(7);
-                lds_barrier();                         // every wave's Z rows are staged
-                PHASE_MARK(8);
-                rows();
-                lds_barrier();                         // the staged rows may be overwritten by the next iteration
-                PHASE_MARK(9);
-                // the other waves are entering their next work item and raise their priority to 1 during MFMA bursts: at priority 0 this
-                // short chain would run behind them and make its wave the straggler of the next rendezvous
-                __builtin_amdgcn_s_setprio(2);
-                PESTO_FIN_MFMA(h, w0[0], zh[0], zl[0])
-                PESTO_FIN_MFMA(h, w0[1], zh[1], zl[1])
-                sat_probe(sat, h[0][0]);
-                // prepare phase: the nqm tables take the registers of w0 and the Z operands (dead now); their round trip overlaps
-                // the rest of the qpm chain - this role has no room for them before the rendezvous
-                __builtin_amdgcn_sched_barrier(0);
-                const float* nq = W + lwp.h_n0 + lane_f * 4;   // fragments n0 [m 2][kgp 2] | n1 [m 2] | n2 [1], (hi, lo) pairs of 256 floats
-                f16x8 n0[2][4], n1[4], n2[2];
-                f32x4 hq[2], tq[2], qq[1];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp) { n0[kgp][2 * m] = ld8h(nq + ((m * 2 + kgp) * 2) * 256); n0[kgp][2 * m + 1] = ld8h(nq + ((m * 2 + kgp) * 2 + 1) * 256); }
-#pragma unroll
-                for (int f = 0; f < 4; ++f) n1[f] = ld8h(nq + (8 + f) * 256);
-                n2[0] = ld8h(nq + 12 * 256); n2[1] = ld8h(nq + 13 * 256);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) { hq[m] = ld4(W + lwp.n_bn0 + 16 * m + 4 * fg); tq[m] = ld4(W + lwp.n_bn1 + 16 * m + 4 * fg); }
-                qq[0] = ld4(W + lwp.n_bn2 + 4 * fg);
-                __builtin_amdgcn_sched_barrier(0);
-                f16x8 xh, xl;
-                split8(elu4(h[0]), elu4(h[1]), xh, xl);
-                PESTO_FIN_MFMA(b1v, w1, xh, xl)
-                sat_probe(sat, b1v[0][0]);
-                split8(elu4(b1v[0]), elu4(b1v[1]), xh, xl);
-                PESTO_FIN_MFMA(b2v, w2, xh, xl)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) st[m] += b2v[m];
-                sat_probe(sat, st[0][0]);          // (unused columns were fed zeros and the sink row's finite state)
-                if (valid) mag_flush_at(st[0], st[1], st_limit, flags, ci);
-                if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
-                if (valid) { float* dst = q_out + (size_t)ci * S; st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]); }
-                PHASE_MARK(10);
-                if (prep) {
-                    post(tile, 0, st);
-                    wait_posts(tile);
-                    f16x8 xnh[2], xnl[2];
-                    node_input(tile, xnh, xnl);
-                    // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12                                    (:119)
-                    PESTO_FIN_MFMA(hq, n0[0], xnh[0], xnl[0])
-                    PESTO_FIN_MFMA(hq, n0[1], xnh[1], xnl[1])
-                    sat_probe(sat, hq[0][0]);
-                    split8(elu4(hq[0]), elu4(hq[1]), xh, xl);
-                    PESTO_FIN_MFMA(tq, n1, xh, xl)
-                    sat_probe(sat, tq[0][0]);
-                    split8(elu4(tq[0]), elu4(tq[1]), xh, xl);
-                    qq[0] = MFMA16(n2[0], xh, qq[0]); qq[0] = MFMA16(n2[0], xl, qq[0]); qq[0] = MFMA16(n2[1], xh, qq[0]);
-                    sat_probe(sat, qq[0][0]);
-                    if (valid) st4(cen + 512 + 4 * fg, qq[0]);
-                }
-            } else {           // ppm: 64 -> 32, no bias, xyz component role - 1             (:148, :152)
-                f16x8 wp[2][4];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp) { wp[kgp][2 * m] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2) * 256); wp[kgp][2 * m + 1] = ld8h(fb + 4096 + ((m * 2 + kgp) * 2 + 1) * 256); }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) st[m] = ld4(p_state + (size_t)ci * 96 + (role - 1) * 32 + 16 * m + 4 * fg);
-                // prepare phase: the G fragments (eight output blocks, K = 32), (hi, lo) pairs of 256 floats
-                f16x8 gw[8][2];
-                {
-                    const float* Lgc = W + lwp.h_gc + lane_f * 4;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { gw[j][0] = ld8h(Lgc + (j * 2) * 256); gw[j][1] = ld8h(Lgc + (j * 2 + 1) * 256); }
-                }
-                PHASE_MARK(7);
-                lds_barrier();
-                PHASE_MARK(8);
-                rows();
-                lds_barrier();
-                PHASE_MARK(9);
-                __builtin_amdgcn_s_setprio(2);
-                h[0] = f32x4{0, 0, 0, 0}; h[1] = h[0];
-                PESTO_FIN_MFMA(h, wp[0], zh[0], zl[0])
-                PESTO_FIN_MFMA(h, wp[1], zh[1], zl[1])
-#pragma unroll
-                for (int m = 0; m < 2; ++m) st[m] += h[m];
-                sat_probe(sat, st[0][0]);
-                if (valid) mag_flush_at(st[0], st[1], st_limit, flags, ci);
-                if (ci == 0) { st[0] = f32x4{0, 0, 0, 0}; st[1] = st[0]; }                               // :239-240 sink
-                if (valid) { float* dst = p_out + (size_t)ci * 96 + (role - 1) * 32; st4(dst + 4 * fg, st[0]); st4(dst + 16 + 4 * fg, st[1]); }
-                PHASE_MARK(10);
-                if (prep) {
-                    post(tile, role, st);
-                    f16x8 ph, pl;
-                    split8(st[0], st[1], ph, pl);
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        f32x4 a[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = f32x4{0, 0, 0, 0};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[4 * half + j][0], ph, a[j]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[4 * half + j][0], pl, a[j]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(gw[4 * half + j][1], ph, a[j]);
-                        sat_probe(sat, a[0][0]);
-                        if (valid) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) st4_finite(cen + (4 * half + j) * 64 + (role - 1) * 16 + 4 * fg, a[j]);
-                        }
-                    }
-                }
-            }
-            if (valid) sat_flush_at(sat, flags, ci);      // (the probes of this phase are MFMA column fe = centre ci)
-            sat = 0.0f;
-            __builtin_amdgcn_s_setprio(0);
-            PHASE_MARK(11);
-        } else {       // waves without a finish role: the [U | A] blocks 4j .. 4j+3 of every tile (U = blocks 0..7 carries b1, A = 8..15)
-            const int ob = 4 * (wave_u - 4 * NTILE);
-            f16x8 ua[2][4][2];                    // [kgp][block][hi|lo]
-            f32x4 ub[4];
-            {
-                const float* Lua = W + lwp.h_ua + lane_f * 4;        // [m 16][kgp 2][hi|lo][256]
-#pragma unroll
-                for (int kgp = 0; kgp < 2; ++kgp)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float* fr = Lua + (size_t)(((ob + j) * 2 + kgp) * 2) * 256;
-                        ua[kgp][j][0] = ld8h(fr); ua[kgp][j][1] = ld8h(fr + 256);
-                    }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ub[j] = ob < 8 ? ld4(W + lwp.n_b1s + 16 * (ob + j) + 4 * fg) : f32x4{0, 0, 0, 0};
-            }
-            lds_barrier();
-            PHASE_MARK(8);
-            lds_barrier();
-            PHASE_MARK(9);
-            if (prep) {
-                __builtin_amdgcn_s_setprio(2);
-#pragma unroll 1
-                for (int tile = 0; tile < NTILE; ++tile) {
-                    int cw, cr, ci; bool valid;
-                    centre_of(tile, fe, cw, cr, ci, valid);
-                    wait_posts(tile);
-                    f16x8 xnh[2], xnl[2];
-                    node_input(tile, xnh, xnl);
-                    f32x4 a[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] = ub[j];
-#pragma unroll
-                    for (int kgp = 0; kgp < 2; ++kgp) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnh[kgp], a[j]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][0], xnl[kgp], a[j]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = MFMA16(ua[kgp][j][1], xnh[kgp], a[j]);
-                    }
-                    sat_probe(sat, a[0][0]);
-                    if (valid) sat_flush_at(sat, flags, ci);
-                    sat = 0.0f;
-                    if (valid) {
-                        float* cen = rec_cen_out + (size_t)ABL_ST(ci) * REC_CEN;
-                        float* nb = rec_nb_out + (size_t)ABL_ST(ci) * REC_A;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (ob < 8) st4_finite(cen + (ob + j) * 64 + 3 * 16 + 4 * fg, a[j]);
-                            else st4(nb + (ob + j - 8) * 16 + 4 * fg, a[j]);                   // A_j[16 fb + 4g + r]
-                        }
-                    }
-                }
-                __builtin_amdgcn_s_setprio(0);
-            }
-            PHASE_MARK(11);
-        }
-#undef PESTO_FIN_MFMA
+#define PESTO_FINR_ON (FIN && !NODEW)
+#define PESTO_FINR_W WPB
+#define PESTO_FINR_GEN 0
+#define PESTO_FINR_ITER fin_iter
+#include "pesto_fin_rendezvous.inc"
+#undef PESTO_FINR_ON
+#undef PESTO_FINR_W
+#undef PESTO_FINR_GEN
+#undef PESTO_FINR_ITER
         ++fin_iter;
       }
       if (NODEW) {
@@ -3327,6 +3061,28 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         // first tile as soon as ITS eight waves have staged)
         lds_signal(&sm.xflag[((NWT > 1 && wave_u >= 8) ? XF_READY2 : XF_READY) + gen], lane == 0);
         ++fin_iter;
+      }
+    }
+    if constexpr (TAILR) {
+      if (fin_iter > 0) {      // the item waves (the node waves have returned from their loop): finish + prepare of the last iteration's 16 centres
+        int tid_t = threadIdx.x;
+        asm volatile("" : "+v"(tid_t));
+        const int lane = tid_t & 63, wave = tid_t >> 6;
+        const bool tail = w_end - last_it < nbx * NE * SUBS;
+        const int sstride = tail ? nbx * NE : NE;
+        const int base = last_it + jb * NE * (tail ? 1 : SUBS);
+        (void)sstride;
+        // (the first barrier of the phase also waits for the node waves to END: a wave that has not terminated counts for s_barrier, and
+        // they are one tile behind - their last posts precede this phase's, whose counter target continues theirs)
+#define PESTO_FINR_ON TAILR
+#define PESTO_FINR_W NE
+#define PESTO_FINR_GEN ((fin_iter - 1) & 1)
+#define PESTO_FINR_ITER (fin_iter - 1)
+#include "pesto_fin_rendezvous.inc"
+#undef PESTO_FINR_ON
+#undef PESTO_FINR_W
+#undef PESTO_FINR_GEN
+#undef PESTO_FINR_ITER
       }
     }
     if (F16) sat_flush(sat + sat_b, flags);      // (nothing is left here: every probe has been flushed with its centre)
