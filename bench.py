@@ -123,7 +123,7 @@ def load_weights(config):
 def source_hash():
     """sha256 over the kernel sources: stamps the PMC-derived traffic file so that a stale one is detectable."""
     h = hashlib.sha256()
-    for f in ("pesto_layer_mfma.hip", "pesto_fin_rendezvous.inc", "pesto_kernels.hip", "pesto_api.hip", "pesto_schema.cpp", "pesto_schema.h", "pesto_kernels.h"):
+    for f in ("pesto_node.hip", "pesto_edge.hip", "pesto_mfma_common.h", "pesto_fin_rendezvous.inc", "pesto_edge_node_waves.inc", "pesto_kernels.hip", "pesto_api.hip", "pesto_schema.cpp", "pesto_schema.h", "pesto_kernels.h"):
         h.update(open(os.path.join(ROOT, "pesto_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -387,7 +387,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="testing only: every rank uses GPU 0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
-    ap.add_argument("--edge-mode", type=int, default=0, help="developer: pesto_debug_edge_mode (0 = per launch, 1 rendezvous, 2 node waves, 3 32-edge tiles)")
+    ap.add_argument("--edge-mode", type=int, default=0, help="developer: pesto_debug_edge_mode (0 = per launch, 1 rendezvous, 2 node waves)")
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="atom numbering of the synthetic clouds: generation order, or along a Z-order curve")
     args = ap.parse_args()

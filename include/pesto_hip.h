@@ -273,10 +273,7 @@ int pesto_mask_to_segments(pesto_model* m, int64_t N, int64_t R, const float* M,
 int pesto_debug_select(pesto_model* m, int32_t layer_kernels, int32_t knn_brute_force);
 /* work decomposition of the shipped state-update kernel: 0 = chosen per launch (default), 1 = rendezvous mode (every wave of a workgroup
  * processes centres, the finish / prepare phase runs behind workgroup rendezvous), 2 = node-wave mode (four waves of twelve only
- * finish / prepare). Both run the same arithmetic in the same order: results must not depend on the choice (tests force each).
- * Developer variants kept for measurement (parity-tested, never chosen by mode 0; another summation order, so not bit-identical):
- * 3 = 32-edge tiles on v_mfma_f32_32x32x16_f16 (one pass per tile, staged gathers; nn >= 16), 4 / 5 = unfused layers (attention sums
- * through memory, output MLPs and records by the node kernel) with 32- / 16-edge tiles. */
+ * finish / prepare). Both run the same arithmetic in the same order: results must not depend on the choice (tests force each). */
 int pesto_debug_edge_mode(pesto_model* m, int32_t mode);
 
 /* ---- per-stage entry points (HOST pointers), used by tests/ to pin each stage against the oracle ----

@@ -10,8 +10,8 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["pesto_schema.cpp", "pesto_kernels.hip", "pesto_layer_mfma.hip", "pesto_api.hip"]
-HEADERS = ["pesto_schema.h", "pesto_kernels.h", "pesto_fin_rendezvous.inc", os.path.join("..", "..", "include", "pesto_hip.h")]
+SOURCES = ["pesto_schema.cpp", "pesto_kernels.hip", "pesto_node.hip", "pesto_edge.hip", "pesto_api.hip"]
+HEADERS = ["pesto_schema.h", "pesto_kernels.h", "pesto_mfma_common.h", "pesto_fin_rendezvous.inc", "pesto_edge_node_waves.inc", os.path.join("..", "..", "include", "pesto_hip.h")]
 OUT = os.path.join(HERE, "libpesto_hip.so")
 # host-only structure I/O library (include/pesto_io.h): plain C++, no HIP runtime, safe in forked data-loader workers
 IO_SOURCE = "pesto_io.cpp"

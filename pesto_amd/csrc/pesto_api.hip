@@ -87,6 +87,8 @@ struct pesto_model {
     DevBuf col_seg, col_segend;            // pesto_forward_batch: structure of every atom, end offset of every structure
     DevBuf in_X, in_ids, in_q0, in_roa;   // staging for host-pointer calls
     DevBuf in_M, mask_seen;               // pesto_mask_to_segments: host mask staging, one word per residue column
+    bool mask_seen_clean = false;         // the buffer has been cleared since it was (re)allocated
+    int mask_gen = 0;                     // generation number the valid rows of a call mark their column with (no clearing launch)
     DevBuf knn_off;                       // structure offsets of the last pesto_knn_collate call
     DevBuf knn_grids, knn_cnt, knn_cur, knn_cell, knn_sorted;   // cell grid of the large structures (pesto_knn_collate)
     DevBuf col_meta, col_ids, col_roa;    // pesto_forward_batch: per-structure table, collated ids / residue columns
@@ -260,7 +262,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
                  ClearArgs{m->flags.as<int>(), 2, m->dmax.as<int>(), (int)(clear_bytes / 4), m->sflags.as<int>(), masked ? 0 : (int)n_dmax}, sc);
     // small launches of the shipped path: pass 2 of the geometry rides in the node launch that writes the first layer's records (one
     // dependent launch less per forward: 38 -> 37)
-    const bool merge_u2 = !exact && m->impl == 2 && m->edge_mode < 4 && unpack2_merge_blocks((int)NT, N1) > 0;
+    const bool merge_u2 = !exact && m->impl == 2 && unpack2_merge_blocks((int)NT, N1) > 0;
     launch_unpack(st, (int)a.N, (int)a.F, a.k, a.X, a.xs_frame, a.xs_atom, a.ids, a.ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(),
                   dmax_ptr(m), err_ptr(m), a.seg_of_atom, a.seg_end, sb, merge_u2);
     if (a.F > 1) launch_expand_roa(st, (int)a.N, (int)a.R, (int)a.F, a.roa, m->roa_f.as<int>(), err_ptr(m));
@@ -279,24 +281,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
         return hipEventRecord(m->kev[kevi++], st);
     };
     auto nn_class = [](int nn) { return nn == 8 ? 1 : nn == 16 ? 2 : nn == 32 ? 3 : 4; };
-    if (m->impl == 2 && edge_variant == 0 && m->edge_mode >= 4) {
-        // developer mode 4: UNFUSED f16-split layers - per layer one edge launch (Z through memory) and one node launch (finish layer l,
-        // records of layer l + 1), state updated in place; measures what the in-kernel finish / prepare phases cost or save
-        for (int l = 0; l < m->cfg.n_layers; ++l) {
-            HIP_TRY(mark(0));
-            launch_node(st, m->W, l > 0 ? &m->img.layers[l - 1] : nullptr, &m->img.layers[l], N1, q[0], p[0], m->zrec.as<float>(),
-                        m->rec_nb.as<float>(), m->rec_cen.as<float>(), 0, err_ptr(m));
-            HIP_TRY(mark(nn_class(m->cfg.nn[l])));
-            launch_edge(st, m->W, m->img.layers[l], N1, m->ids_s.as<int>(), m->geo.as<float4>(), m->rec_nb.as<float>(),
-                        m->rec_cen.as<float>(), p[0], m->zrec.as<float>(), m->edge_blocks, 0, err_ptr(m), nullptr, nullptr, nullptr, nullptr, nullptr,
-                        nullptr, m->edge_mode);
-        }
-        HIP_TRY(mark(0));
-        launch_node(st, m->W, &m->img.layers[m->cfg.n_layers - 1], nullptr, N1, q[0], p[0], m->zrec.as<float>(), m->rec_nb.as<float>(),
-                    m->rec_cen.as<float>(), 0, err_ptr(m));
-        HIP_TRY(mark(-1));
-        if (detail) { m->kev.resize(kevi); m->kev_class.resize(kevi); }
-    } else if (m->impl == 2 && edge_variant == 0) {
+    if (m->impl == 2 && edge_variant == 0) {
         // shipped path: ONE node launch (the first layer's records), then one edge launch per layer - edges and attention, the layer's
         // output MLPs (finish phase: new state into the other half of the ping-pong pair) and the NEXT layer's records (prepare phase).
         // Neighbour records (gathered by every workgroup) ping-pong; the centre records are rewritten in place (only the wave that
@@ -345,7 +330,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
     }
     if (m->timing) {
         HIP_TRY(hipEventRecord(m->ev[2], st));
-        m->n_layer_launches = m->impl != 2 ? m->cfg.n_layers : (edge_variant == 0 && m->edge_mode < 4) ? m->cfg.n_layers + 1 : 2 * m->cfg.n_layers + 1;
+        m->n_layer_launches = m->impl != 2 ? m->cfg.n_layers : edge_variant == 0 ? m->cfg.n_layers + 1 : 2 * m->cfg.n_layers + 1;
         m->have_timing = true;
     }
     // The flags word is FINAL here: bad ids / residue columns are found by the unpack (and frame-expansion) launches, the range guard fires
@@ -490,7 +475,6 @@ int pesto_destroy(pesto_model* m) {
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     (void)hipDeviceSynchronize();
-    debug_print_phase_cycles();
     for (auto& b : m->slot) {
         if (b.ev_h2d) (void)hipEventDestroy(b.ev_h2d);
         if (b.ev_done) (void)hipEventDestroy(b.ev_done);
@@ -590,8 +574,7 @@ int pesto_debug_host_only(pesto_model* m, int32_t enabled) {
 
 int pesto_debug_edge_mode(pesto_model* m, int32_t mode) {
     if (check_model(m)) return PESTO_ERR_INVALID;
-    if (mode < 0 || mode > 5)
-        return fail(PESTO_ERR_INVALID, "mode must be 0 (per launch), 1 (rendezvous), 2 (node waves), 3 (32-edge tiles), 4 (unfused, 32-edge tiles) or 5 (unfused, 16-edge tiles)");
+    if (mode < 0 || mode > 2) return fail(PESTO_ERR_INVALID, "mode must be 0 (per launch), 1 (rendezvous) or 2 (node waves)");
     m->edge_mode = mode;
     return 0;
 }
@@ -1124,11 +1107,17 @@ int pesto_mask_to_segments(pesto_model* m, int64_t N, int64_t R, const float* M,
     if (N < 1 || R < 1 || N > 0x7ffffff0 / 96 || R > N || !M || !res_of_atom_out) return fail(PESTO_ERR_INVALID, "bad arguments");
     if (ptr_kind != PESTO_PTR_HOST && ptr_kind != PESTO_PTR_DEVICE) return fail(PESTO_ERR_INVALID, "ptr_kind must be PESTO_PTR_HOST or PESTO_PTR_DEVICE");
     HIP_TRY(hipSetDevice(m->device));
+    const size_t cap0 = m->mask_seen.cap;
     if (m->mask_seen.ensure((size_t)R * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
+    if (m->mask_seen.cap != cap0 || m->mask_gen == 0x7fffffff) m->mask_seen_clean = false;      // a fresh buffer holds anything: cleared once (on the call's stream), generations restart
+    const bool fresh = !m->mask_seen_clean;
+    if (fresh) m->mask_gen = 0;
+    const int gen = ++m->mask_gen;
     if (ptr_kind == PESTO_PTR_DEVICE) {
         Sequence seq(m, (hipStream_t)stream);
         if (seq.rc) return seq.rc;
-        launch_mask_to_segments((hipStream_t)stream, (int)N, (int)R, M, res_of_atom_out, m->mask_seen.as<int>());
+        if (fresh) { HIP_TRY(hipMemsetAsync(m->mask_seen.p, 0, m->mask_seen.cap, (hipStream_t)stream)); m->mask_seen_clean = true; }
+        launch_mask_to_segments((hipStream_t)stream, (int)N, (int)R, M, res_of_atom_out, m->mask_seen.as<int>(), gen);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -1137,7 +1126,8 @@ int pesto_mask_to_segments(pesto_model* m, int64_t N, int64_t R, const float* M,
     Sequence seq(m, st);
     if (seq.rc) return seq.rc;
     HIP_TRY(hipMemcpyAsync(m->in_M.p, M, (size_t)N * R * 4, hipMemcpyHostToDevice, st));
-    launch_mask_to_segments(st, (int)N, (int)R, m->in_M.as<float>(), m->in_roa.as<int>(), m->mask_seen.as<int>());
+    if (fresh) { HIP_TRY(hipMemsetAsync(m->mask_seen.p, 0, m->mask_seen.cap, st)); m->mask_seen_clean = true; }
+    launch_mask_to_segments(st, (int)N, (int)R, m->in_M.as<float>(), m->in_roa.as<int>(), m->mask_seen.as<int>(), gen);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(res_of_atom_out, m->in_roa.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

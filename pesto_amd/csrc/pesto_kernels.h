@@ -1,4 +1,4 @@
-// pesto_kernels.h - launchers of the gfx950 kernels (definitions in pesto_kernels.hip / pesto_layer_mfma.hip)
+// pesto_kernels.h - launchers of the gfx950 kernels (definitions in pesto_kernels.hip / pesto_node.hip / pesto_edge.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -49,7 +49,7 @@ int unpack2_merge_blocks(int n_atoms, int N1);
 void launch_expand_roa(hipStream_t st, int Nf, int R, int F, const int* roa, int* roa_f, int* err_flag);
 void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                      const float* q_in, const float* p_in, float* q_out, float* p_out);
-// MFMA layer (pesto_layer_mfma.hip): per-atom node kernel (finish previous layer / prepare records) + edge kernel.
+// MFMA layer (pesto_node.hip, pesto_edge.hip): per-atom node kernel (finish previous layer / prepare records) + edge kernel.
 // flags: the flags word (the SatCtx of the launch lies behind it); the f16-split kernels set bit 2 (value 4) of it and of the
 // structure's word when an activation left the f16 range (sat_probe)
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
@@ -86,9 +86,8 @@ void launch_onehot(hipStream_t st, int N, int n0, int n_idx, const unsigned char
 void launch_segments(hipStream_t st, int n_total, int n_struct, const int* seg_end, int* seg_of_atom);
 // dense mask M [N,R] -> roa [N] (column of the single member per row, -1 for rows with != 1 member; roa[0] = -1 if a column is empty);
 // seen: R ints of scratch
-void launch_mask_to_segments(hipStream_t st, int N, int R, const float* M, int* roa, int* seen);
+void launch_mask_to_segments(hipStream_t st, int N, int R, const float* M, int* roa, int* seen, int gen);
 void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z, const int* roa, float* p_out, float* bf_out, int* err_flag);
-void debug_print_phase_cycles();   // no-op unless built with -DPESTO_PROFILE_PHASES
 // sc (optional): a residue whose structure has its range-guard word set gets NaN logits; only_flagged: ONLY those residues are written
 // (the fp32 repeat of PESTO_PRECISION_AUTO: the other structures keep the logits of the split kernels)
 void launch_pool(hipStream_t st, const float* W, const ModelW& mw, int n_out, int N, int R, const float* q, const float* p,

@@ -1,5 +1,5 @@
 // pesto_kernels.hip - gfx950 kernels of the PeSTo forward pass: embedding, geometry unpack, the v1
-// state-update layer (LDS-tiled fp32 VALU; the MFMA layer lives in pesto_layer_mfma.hip), residue pool + decoder.
+// state-update layer (LDS-tiled fp32 VALU; the MFMA layer lives in pesto_node.hip / pesto_edge.hip), residue pool + decoder.
 //
 // Math restated from the reference (file:line relative to /root/reference):
 //   embedding              model/model.py:34
@@ -1027,50 +1027,61 @@ __global__ __launch_bounds__(256) void k_postprocess(int N, int R, int n_out, co
 }
 
 // Dense residue mask -> segments (Model.forward's M argument, model/model.py:32; one 1 per row by construction, src/data_encoding.py:73).
-// One wave per row: the lanes sweep the R columns (16-byte loads when the row is 16-byte aligned), count the members (> 0.5, as the
-// host check does) and keep the column of the last one; a row with exactly one member gets its column, any other row -1. Every valid
-// row marks its column in `seen`; k_mask_check poisons roa[0] when a column stayed empty. No host round trip: a poisoned entry fails
-// the residue-column check of the forward that consumes the array.
-__global__ __launch_bounds__(256) void k_mask_to_segments(int N, int R, const float* __restrict__ M, int* __restrict__ roa, int* __restrict__ seen) {
+// HBM-read-bound: the mask of the headline batch is 288 MB (24,000 x 3,000 fp32), the answer 96 KB. One wave per row at a time, the
+// lanes sweep the row's columns with 16-byte loads FOUR batches deep (4 x 1 KB of a row in flight per wave, eight waves per SIMD - a
+// plain load - compare loop kept one load in flight and ran at 2.3 TB/s), count the members (> 0.5, as the host check does) and keep the
+// column of the last one; a row with exactly one member gets its column, any other row -1. Workgroups stride over the rows (a grid of
+// 2,048 workgroups instead of one per four rows: no tail of tiny workgroups). Every valid row marks its column in `seen` with the
+// call's generation number (no clearing launch); k_mask_check poisons roa[0] when a column stayed empty. No host round trip: a
+// poisoned entry fails the residue-column check of the forward that consumes the array.
+__device__ __forceinline__ void mask_scan4(const float4 v, int c4, int& cnt, int& col) {
+    if (v.x > 0.5f) { ++cnt; col = 4 * c4; }
+    if (v.y > 0.5f) { ++cnt; col = 4 * c4 + 1; }
+    if (v.z > 0.5f) { ++cnt; col = 4 * c4 + 2; }
+    if (v.w > 0.5f) { ++cnt; col = 4 * c4 + 3; }
+}
+__global__ __launch_bounds__(256) void k_mask_to_segments(int N, int R, const float* __restrict__ M, int* __restrict__ roa, int* __restrict__ seen, int gen) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= N) return;
-    const float* row = M + (size_t)i * R;
-    int cnt = 0, col = -1;
-    int c0 = 0;
-    if ((((size_t)row) & 15) == 0) {
-        const int R4 = R >> 2;
-        const float4* row4 = reinterpret_cast<const float4*>(row);
-        for (int c = lane; c < R4; c += 64) {
-            const float4 v = row4[c];
-            if (v.x > 0.5f) { ++cnt; col = 4 * c; }
-            if (v.y > 0.5f) { ++cnt; col = 4 * c + 1; }
-            if (v.z > 0.5f) { ++cnt; col = 4 * c + 2; }
-            if (v.w > 0.5f) { ++cnt; col = 4 * c + 3; }
+    const int R4 = R >> 2;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < N; i += gridDim.x * 4) {
+        const float* row = M + (size_t)i * R;
+        int cnt = 0, col = -1;
+        int c0 = 0;
+        if ((((size_t)row) & 15) == 0) {
+            const float4* row4 = reinterpret_cast<const float4*>(row);
+            for (int c = lane; c < R4; c += 256) {
+                const float4 v0 = row4[c];
+                const float4 v1 = c + 64 < R4 ? row4[c + 64] : zero4;
+                const float4 v2 = c + 128 < R4 ? row4[c + 128] : zero4;
+                const float4 v3 = c + 192 < R4 ? row4[c + 192] : zero4;
+                mask_scan4(v0, c, cnt, col); mask_scan4(v1, c + 64, cnt, col); mask_scan4(v2, c + 128, cnt, col); mask_scan4(v3, c + 192, cnt, col);
+            }
+            c0 = R4 << 2;
         }
-        c0 = R4 << 2;
-    }
-    for (int c = c0 + lane; c < R; c += 64)
-        if (row[c] > 0.5f) { ++cnt; col = c; }
+        for (int c = c0 + lane; c < R; c += 64)
+            if (row[c] > 0.5f) { ++cnt; col = c; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        cnt += __shfl_xor(cnt, o);
-        col = max(col, __shfl_xor(col, o));
-    }
-    if (lane == 0) {
-        const bool ok = cnt == 1;
-        roa[i] = ok ? col : -1;
-        if (ok) seen[col] = 1;
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_xor(cnt, o);
+            col = max(col, __shfl_xor(col, o));
+        }
+        if (lane == 0) {
+            const bool ok = cnt == 1;
+            roa[i] = ok ? col : -1;
+            if (ok) seen[col] = gen;
+        }
     }
 }
-__global__ __launch_bounds__(256) void k_mask_check(int R, const int* __restrict__ seen, int* __restrict__ roa) {
+__global__ __launch_bounds__(256) void k_mask_check(int R, const int* __restrict__ seen, int* __restrict__ roa, int gen) {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < R && seen[r] == 0) roa[0] = -1;      // (benign race: every writer stores the same value)
+    if (r < R && seen[r] != gen) roa[0] = -1;      // (benign race: every writer stores the same value)
 }
-void launch_mask_to_segments(hipStream_t st, int N, int R, const float* M, int* roa, int* seen) {
-    (void)hipMemsetAsync(seen, 0, (size_t)R * sizeof(int), st);
-    hipLaunchKernelGGL(k_mask_to_segments, dim3((N + 3) / 4), dim3(256), 0, st, N, R, M, roa, seen);
-    hipLaunchKernelGGL(k_mask_check, dim3((R + 255) / 256), dim3(256), 0, st, R, seen, roa);
+// gen: a number that differs from the one of the previous call on the same `seen` buffer (and from what a fresh buffer holds)
+void launch_mask_to_segments(hipStream_t st, int N, int R, const float* M, int* roa, int* seen, int gen) {
+    const int rows4 = (N + 3) / 4;
+    hipLaunchKernelGGL(k_mask_to_segments, dim3(rows4 < 2048 ? rows4 : 2048), dim3(256), 0, st, N, R, M, roa, seen, gen);
+    hipLaunchKernelGGL(k_mask_check, dim3((R + 255) / 256), dim3(256), 0, st, R, seen, roa, gen);
 }
 
 void launch_postprocess(hipStream_t st, int N, int R, int n_out, const float* z, const int* roa, float* p_out, float* bf_out, int* err_flag) {

@@ -173,23 +173,6 @@ int32_t put_frags_f16_linear(std::vector<float>& img, const Mat& M, int n_m, int
     memcpy(&img[off], h.data(), h.size() * sizeof(_Float16));
     return (int32_t)off;
 }
-// f16 hi/lo fragment table for v_mfma_f32_32x32x16_f16 (layout: pesto_schema.h, EL32_*), appended to img
-void put_frags32_f16(std::vector<float>& img, const Mat& M, int n_mb, int n_ks, bool linear) {
-    std::vector<_Float16> h;
-    for (int mb = 0; mb < n_mb; ++mb)
-        for (int ks = 0; ks < n_ks; ++ks)
-            for (int part = 0; part < 2; ++part)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int col = linear ? 16 * ks + 8 * (lane >> 5) + j : 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-                        const float w = M.get(32 * mb + (lane & 31), col);
-                        const _Float16 hi = (_Float16)w;
-                        h.push_back(part == 0 ? hi : (_Float16)(w - (float)hi));
-                    }
-    const size_t off = img.size();
-    img.resize(off + h.size() / 2);
-    memcpy(&img[off], h.data(), h.size() * sizeof(_Float16));
-}
 int32_t put_vec(std::vector<float>& img, const float* src, int n, int pad_to = 0) {
     int32_t off = (int32_t)img.size();
     img.insert(img.end(), src, src + n);
@@ -335,37 +318,6 @@ DeviceImage build_device_image(const pesto_config& c, const float* blob) {
                 for (int c = 0; c < 32; ++c) W1p.at(f, c) = W1.get(f, 161 + c);
             const int32_t off = put_frags_f16_linear(img, W1p.scaled(LOG2E), 8, 1);      // appended right behind the 11600-float image
             if (off != W.e_lds16 + EL_W1P) abort();
-        }
-        {   // LDS image of the 32-edge-tile kernel (EL32_*): same numbers, fragments of v_mfma_f32_32x32x16_f16
-            pad16(img);
-            W.e_lds32 = (int32_t)img.size();
-            Mat W1p(128, 32), Weq2(32, 32), Wep2(32, 32), Wev2(64, 64), Wv3(64, 64), Wk32(32, 64);
-            for (int f = 0; f < 128; ++f)
-                for (int c = 0; c < 32; ++c) W1p.at(f, c) = W1.get(f, 161 + c);
-            put_block(Weq2, 0, 0, blob, L.eqkm.l[1], 0, 32);
-            put_block(Wep2, 0, 0, blob, L.epkm.l[1], 0, 32);
-            put_block(Wev2, 0, 0, blob, L.evm.l[1], 0, 64);
-            put_block(Wv3, 0, 0, blob, L.evm.l[2], 0, 64);
-            for (int r = 0; r < 16; ++r)
-                for (int c = 0; c < 64; ++c) Wk32.at(r, c) = Wk16.get(r, c);
-            put_frags32_f16(img, W1p.scaled(LOG2E), 4, 2, true);
-            put_frags32_f16(img, Weq2, 1, 2, false);
-            put_frags32_f16(img, Wep2, 1, 2, false);
-            put_frags32_f16(img, Wev2, 2, 4, false);
-            put_frags32_f16(img, Wk32.scaled(1.0f / LOG2E), 1, 4, false);
-            put_frags32_f16(img, Wv3.scaled(1.0f / LOG2E), 2, 4, false);
-            for (int f = 0; f < 128; ++f) img.push_back(b2[f] * LOG2E);
-            for (int r = 0; r < 32; ++r) img.push_back(r < 16 ? img[W.e_lds + EL_BK + r] : 0.0f);
-            put_vec(img, blob + L.evm.l[2].b, 64);
-            for (int f = 0; f < 128; ++f) {
-                const float wd = W1.get(f, 0) * LOG2E;
-                const _Float16 hi = (_Float16)wd, lo = (_Float16)(wd - (float)hi), z = (_Float16)0.0f;
-                const _Float16 a[2] = {hi, lo}, b[2] = {hi, z};
-                float fa, fb;
-                memcpy(&fa, a, 4); memcpy(&fb, b, 4);
-                img.push_back(fa); img.push_back(fb);
-            }
-            if ((int32_t)img.size() != W.e_lds32 + EDGE_LDS_FLOATS_32) abort();
         }
         // node kernel: finish (qpm, ppm)
         {

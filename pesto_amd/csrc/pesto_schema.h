@@ -34,11 +34,10 @@ struct LayerW {
     MlpW nqm, qpm;
     LinearW ppm;
     int32_t nn;
-    // ---- MFMA path (pesto_layer_mfma.hip). "frag" tables are MFMA operand fragments in the order
+    // ---- MFMA path (pesto_node.hip, pesto_edge.hip). "frag" tables are MFMA operand fragments in the order
     // [out-block m][in-block fb][lane 0..63][r 0..3]: value W[16m + (lane&15)][16fb + 4(lane>>4) + r], so one
     // float4 per lane feeds the four k-steps r of mfma_f32_16x16x4 for (m, fb).
     int32_t e_lds;              // edge-kernel LDS image, EDGE_LDS_FLOATS contiguous floats (layout: EdgeLds below)
-    int32_t e_lds32;            // LDS image of the 32x32x16 edge kernel (EL32_* below): f16 hi/lo fragments for v_mfma_f32_32x32x16_f16
     int32_t e_lds16;            // same image with the value network's layer-2/3 fragments as f16 hi/lo pairs for
                                 // v_mfma_f32_16x16x32_f16: [m][kgroup][hi|lo][lane][8 halves], k(kg, j) = 16(2 kgroup + j/4) + 4kg + j%4
     int32_t n_q0, n_bq0, n_q1, n_bq1, n_q2, n_bq2, n_pp;   // qpm frags [2][4],[2][2],[2][2] + biases[32]; ppm frags [2][4]
@@ -63,24 +62,6 @@ constexpr int EDGE_LDS_FLOATS = EL_WD + 128;   // 11600
 // [mb 8][hi|lo][lane][8 halves] (put_frags_f16_linear)
 constexpr int EL_W1P = EDGE_LDS_FLOATS;
 constexpr int EDGE_LDS_FLOATS_HY = EL_W1P + 8 * 2 * 256;   // 15696
-
-// ---- LDS image of the 32-edge-tile kernel (k_edge<..., M32 = true>; v_mfma_f32_32x32x16_f16). One fragment = 64 lanes x 8 halves = 256
-// floats; every table is [out-block of 32 rows][k-step of 16][hi|lo][lane][j]: value W[32 mb + (lane & 31)][col(ks, lane >> 5, j)] with
-//   chained operand (the k index is a D register of the previous MFMA): col = 16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3)
-//   linear operand  (the kernel gathers eight consecutive inputs)      : col = 16 ks + 8 (lane >> 5) + j
-// (pesto_schema.cpp::put_frags32_f16). Same log2-domain scaling as the e_lds16 image.
-constexpr int EL32_W1P = 0;                        // [mb 4][ks 2][hl 2] linear: W1[:, 161:193], the p_j.r block of edge layer 1
-constexpr int EL32_W2EQ = EL32_W1P + 16 * 256;     // [ks 2][hl 2]: eqkm layer 2 (32 -> 32)
-constexpr int EL32_W2EP = EL32_W2EQ + 4 * 256;     // [ks 2][hl 2]: epkm layer 2
-constexpr int EL32_W2EV = EL32_W2EP + 4 * 256;     // [mb 2][ks 4][hl 2]: evm layer 2 (64 -> 64)
-constexpr int EL32_W3K = EL32_W2EV + 16 * 256;     // [ks 4][hl 2]: key rows 4 part + kappa (rows 16..31 zero), K = [eq h2 | ep h2]
-constexpr int EL32_W3V = EL32_W3K + 8 * 256;       // [cb 2][ks 4][hl 2]: evm layer 3, B-operand orientation (edges are the MFMA rows)
-constexpr int EL32_B2 = EL32_W3V + 16 * 256;       // 128 (log2-scaled)
-constexpr int EL32_BK = EL32_B2 + 128;             // 32 (rows 16..31 zero)
-constexpr int EL32_B3V = EL32_BK + 32;             // 64
-constexpr int EL32_WD = EL32_B3V + 64;             // 128 x 2 dwords: (wd_hi | wd_lo) and (wd_hi | 0) as packed f16 pairs - the distance
-                                                   // column of edge layer 1, k-slots 4..7 of the centre MFMA's second k-group
-constexpr int EDGE_LDS_FLOATS_32 = EL32_WD + 256;  // 16864
 
 // per-atom records written by the node kernel and read by the edge kernel (float counts)
 constexpr int REC_NB = 512;    // [fb 8][g 4][A,C0,C1,C2][r 4]  (p_j itself is gathered from the state array)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer: registers / scratch of every kernel of a source file: profiles/dev/resources.sh [file.hip] [extra flags]
-F=${1:-pesto_amd/csrc/pesto_layer_mfma.hip}; shift
+F=${1:-pesto_amd/csrc/pesto_edge.hip}; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -ffp-contract=on -x hip -c --cuda-device-only -Rpass-analysis=kernel-resource-usage "$@" $F -o /dev/null 2>&1 | python3 -c '
 import re, sys
 name = None

@@ -15,6 +15,28 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target)
     }
     __syncthreads();
 }
+// XCD-hierarchical form (MI355X_MICROARCH.md "barrier-xcd"): workgroup b runs on XCD b % 8. Arrive on the XCD's own counter (its own
+// 128-byte line); the LAST arriver of an XCD (its leader for this round) arrives on the top counter, waits for the eight leaders, and
+// publishes the round in the XCD's generation word, which the other workgroups of the XCD poll (relaxed agent-scope loads + s_sleep from
+// one lane). Release fence before the arrival, acquire fence behind the wait. bar: [8 x 32 counters | top x 32 | 8 x 32 generations].
+__device__ __forceinline__ void grid_barrier_xcd(unsigned* bar, unsigned round1 /* 1-based */) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+        unsigned* cnt = bar + 32 * xcd, *top = bar + 32 * 8, *gen = bar + 32 * 9 + 32 * xcd;
+        __atomic_thread_fence(__ATOMIC_RELEASE);      // agent scope: this workgroup's stores are visible before it counts as arrived
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == per_xcd * round1 - 1) {
+            __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8u * round1) __builtin_amdgcn_s_sleep(1);
+            __hip_atomic_store(gen, round1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round1) __builtin_amdgcn_s_sleep(1);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+}
 __global__ __launch_bounds__(768) void k_rounds(float* buf, int n, unsigned* counter, int rounds, int use_barrier) {
     const int nb = gridDim.x;
     for (int r = 0; r < rounds; ++r) {
@@ -23,18 +45,27 @@ __global__ __launch_bounds__(768) void k_rounds(float* buf, int n, unsigned* cou
         float acc = 0.f;
         for (int i = threadIdx.x; i < n; i += 768) acc += buf[(size_t)src * n + i];
         for (int i = threadIdx.x; i < n; i += 768) buf[(size_t)blockIdx.x * n + i] = acc * 1e-9f + r;
-        if (use_barrier) grid_barrier(counter, (unsigned)(nb * (r + 1)));
+        if (use_barrier == 1) grid_barrier(counter, (unsigned)(nb * (r + 1)));
+        else if (use_barrier == 2) grid_barrier_xcd(counter, (unsigned)(r + 1));
     }
 }
 int main() {
-    const int nb = 256, n = 1024;      // 4 KB per workgroup and round
+    const int nb = 256;
     float* buf; unsigned* cnt;
-    hipMalloc(&buf, (size_t)nb * n * 4); hipMemset(buf, 0, (size_t)nb * n * 4);
-    hipMalloc(&cnt, 4);
+    hipMalloc(&buf, (size_t)nb * 8192 * 4); hipMemset(buf, 0, (size_t)nb * 8192 * 4);
+    hipMalloc(&cnt, 4096);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int R = 2000;
+    for (int n : {1024, 1536, 8192}) {      // floats per workgroup and round: 4 KB, 6 KB (= 1.5 MB per round: one structure's state), 32 KB
+    printf("---- %d bytes written and read per workgroup and round (%.2f MB per round)\n", n * 4, nb * n * 4 / 1e6);
     for (int rep = 0; rep < 2; ++rep) {
-        hipMemset(cnt, 0, 4);
+        hipMemset(cnt, 0, 4096);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_rounds, dim3(nb), dim3(768), 0, 0, buf, n, cnt, R, 2);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        { float ms2; hipEventElapsedTime(&ms2, e0, e1);
+          printf("persistent kernel, %d rounds with the XCD-hierarchical barrier : %.2f us per round\n", R, ms2 * 1e3 / R); }
+        hipMemset(cnt, 0, 4096);
         hipEventRecord(e0);
         hipLaunchKernelGGL(k_rounds, dim3(nb), dim3(768), 0, 0, buf, n, cnt, R, 1);
         hipEventRecord(e1); hipEventSynchronize(e1);
@@ -50,6 +81,7 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         printf("%d separate launches of one round                : %.2f us per round\n", R, ms * 1e3 / R);
+    }
     }
     return 0;
 }

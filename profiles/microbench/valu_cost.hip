@@ -39,6 +39,12 @@ KERNEL(k_adddpp,   "v_add_f32_dpp %[f0], %[f2], %[f0] quad_perm:[1,0,3,2] row_ma
 KERNEL(k_rcp,      "v_rcp_f32 %[f0], %[f0]\n v_rcp_f32 %[f1], %[f1]\n")
 KERNEL(k_readlane, "v_readlane_b32 s10, %[f0], 3\n v_readlane_b32 s11, %[f1], 5\n")
 KERNEL(k_cndmask,  "v_cndmask_b32 %[f0], %[f2], %[f3], vcc\n v_cndmask_b32 %[f1], %[f2], %[f3], vcc\n")
+KERNEL(k_cndmask_s,"v_cndmask_b32_e64 %[f0], %[f2], %[f3], s[10:11]\n v_cndmask_b32_e64 %[f1], %[f2], %[f3], s[10:11]\n")
+KERNEL(k_cndmask_d,"v_cndmask_b32 %[f0], %[f0], %[f3], vcc\n v_cndmask_b32 %[f1], %[f1], %[f3], vcc\n")
+KERNEL(k_and,      "v_and_b32 %[i0], %[i0], %[i1]\n v_and_b32 %[f1], %[f1], %[i1]\n")
+KERNEL(k_bfi,      "v_bfi_b32 %[f0], %[i1], %[f2], %[f0]\n v_bfi_b32 %[f1], %[i1], %[f3], %[f1]\n")
+KERNEL(k_mulf,     "v_mul_f32 %[f0], %[f0], %[f2]\n v_mul_f32 %[f1], %[f1], %[f3]\n")
+KERNEL(k_max,      "v_max_f32 %[f0], %[f0], %[f2]\n v_max_f32 %[f1], %[f1], %[f3]\n")
 KERNEL(k_pkmul,    "v_pk_mul_f32 %[p0], %[p0], %[p1]\n v_pk_add_f32 %[p1], %[p1], %[p0]\n")
 KERNEL(k_pkaddf16, "v_pk_add_f16 %[f0], %[f0], %[f2]\n v_pk_fma_f16 %[f1], %[f1], %[f2], %[f3]\n")
 typedef void (*kern_t)(int, float*);
@@ -57,6 +63,6 @@ int main() {
     const double base = run(k_fma, d);
 #define SHOW(k) { const double t = run(k, d); printf("%-14s %6.3f ns per instruction per SIMD   x%.2f of v_fma_f32\n", #k, t, t / base); }
     SHOW(k_fma) SHOW(k_pkfma) SHOW(k_pkmul) SHOW(k_exp) SHOW(k_exp_fma) SHOW(k_exp_3fma) SHOW(k_rcp) SHOW(k_med3) SHOW(k_cvtpk) SHOW(k_mixlo) SHOW(k_mad64) SHOW(k_lshladd64)
-    SHOW(k_addu32) SHOW(k_mul24) SHOW(k_mullo) SHOW(k_movdpp) SHOW(k_adddpp) SHOW(k_readlane) SHOW(k_cndmask) SHOW(k_pkaddf16)
+    SHOW(k_addu32) SHOW(k_mul24) SHOW(k_mullo) SHOW(k_movdpp) SHOW(k_adddpp) SHOW(k_readlane) SHOW(k_cndmask) SHOW(k_cndmask_s) SHOW(k_cndmask_d) SHOW(k_and) SHOW(k_bfi) SHOW(k_mulf) SHOW(k_max) SHOW(k_pkaddf16)
     return 0;
 }
