@@ -52,8 +52,13 @@ typedef enum pesto_status {
  *               and not on the handle's history either (no "fp32 first after one overflow" switch: a model that overflows on every
  *               input pays the repeat every time; pesto_get_status counts the structures repeated - use PESTO_PRECISION_FP32 for it).
  *               Host-pointer calls (which wait for their D2H copy anyway) repeat before they return. Device-pointer calls also
- *               CHECK BEFORE THEY RETURN (one 4-byte D2H + a stream synchronisation behind the launch), so z_out is final when a
- *               drop-in caller consumes it with further stream work. pesto_set_async_auto(m, 1) trades that for a fully asynchronous
+ *               CHECK BEFORE THEY RETURN: the flags word is final behind the last layer launch, is copied (4 bytes) in front of the
+ *               pool kernels, and the call waits for THAT copy - not for the stream. When the call returns the verdict is known (bad
+ *               inputs have raised, an overflowed structure has been queued again on the exact kernels), but the pool kernels may
+ *               still be reading res_of_atom and writing z_out: z_out is final IN STREAM ORDER on `stream` (what a drop-in caller
+ *               that goes on with further work on that stream needs), and the input / output buffers must stay valid - and must not
+ *               be overwritten from the host or from another stream - until `stream` has passed the call (pesto_synchronize, or a
+ *               stream / event wait of the caller's). pesto_set_async_auto(m, 1) trades the check for a fully asynchronous
  *               call: the flags word is copied to pinned memory behind the launch and looked at by the NEXT call on the handle (any
  *               forward, pesto_postprocess, pesto_get_status, pesto_set_precision, pesto_forward_batch_wait, pesto_synchronize):
  *               bad inputs are reported there (PESTO_ERR_INVALID), a range overflow queues the fp32 repeat of the remembered launch

@@ -24,6 +24,31 @@ def _is_h5(path):
     return os.fspath(path).lower().endswith((".h5", ".hdf5", ".hdf"))
 
 
+def h5_dataset_names(result_keys, keys=None):
+    """{result key -> HDF5 dataset name} as save_results uses it: ``keys`` where given, else the key without leading '/'. Two result keys
+    with the same dataset name ('/a.pdb' and 'a.pdb') raise ValueError - found here, before any work, not in the middle of a write."""
+    out, seen = {}, {}
+    for k in result_keys:
+        n = (keys or {}).get(k, str(k).lstrip("/"))
+        if not n:
+            raise ValueError(f"result key {k!r} has an empty HDF5 dataset name")
+        if n in seen:
+            raise ValueError(f"result keys {seen[n]!r} and {k!r} map to the same HDF5 dataset name {n!r}: pass keys={{key: name}}")
+        seen[n] = k
+        out[k] = n
+    return out
+
+
+def check_results_path(path, result_keys, keys=None):
+    """What can be known about a bulk result file before the work is done: for an HDF5 name, that the HDF5 C library loads here
+    (h5store.H5Unavailable otherwise) and that the dataset names are unique (ValueError). apply_model calls it before its first launch:
+    a run of hours must not end in an exception that loses the computed results."""
+    if path is not None and _is_h5(path):
+        from . import h5store
+        h5store.load()
+        h5_dataset_names(list(result_keys), keys)
+
+
 def save_results(results, path, keys=None):
     """Bulk result file of the reference's interfaceome driver, ``hf[key] = p.cpu().numpy()`` per structure
     (interfaceome/apply_model.py:53-79). The extension picks the container:
@@ -34,17 +59,24 @@ def save_results(results, path, keys=None):
       without its leading '/' (a file path is a valid HDF5 name; the reference's keys are its store's ``pdbid/assembly/chain`` names).
     * anything else: one .npz with the per-structure tables stacked along the residue axis: ``keys`` [n] (str), ``offsets`` [n+1]
       (int64), ``p`` [sum R_i, n_out] (float32) - structure i is p[offsets[i]:offsets[i+1]].
-    Both are written to a temporary file and renamed."""
+    Both are written to a temporary file and renamed; a failed write removes its temporary file. An HDF5 store is read back under its
+    DATASET names (load_results: the default name drops the leading '/' of a path key - h5_dataset_names gives the map)."""
     path = os.fspath(path)
     names = list(results)
     tabs = [np.asarray(results[k], dtype=np.float32).reshape(len(results[k]), -1) for k in names]
     if _is_h5(path):
         from . import h5store
+        dsn = h5_dataset_names(names, keys)      # (raises on two keys with one dataset name BEFORE anything is written)
         tmp = path + ".tmp"
-        with h5store.H5Store(tmp, "w") as hf:
-            for k, t in zip(names, tabs):
-                hf[(keys or {}).get(k, str(k).lstrip("/"))] = t
-        os.replace(tmp, path)
+        try:
+            with h5store.H5Store(tmp, "w") as hf:
+                for k, t in zip(names, tabs):
+                    hf[dsn[k]] = t
+            os.replace(tmp, path)
+        except BaseException:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise
         return path
     n_out = tabs[0].shape[1] if tabs else 0
     offs = np.zeros(len(names) + 1, dtype=np.int64)
@@ -57,7 +89,8 @@ def save_results(results, path, keys=None):
 
 
 def load_results(path):
-    """{key: p [R, n_out]} from a file written by save_results (or, for .h5, by the reference's own loop)."""
+    """{key: p [R, n_out]} from a file written by save_results (or, for .h5, by the reference's own loop). An HDF5 store gives its
+    dataset names as keys (h5_dataset_names: a path key comes back without its leading '/'); the .npz form the keys as they were."""
     if _is_h5(path):
         from . import h5store
         with h5store.H5Store(path) as hf:
@@ -78,6 +111,8 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
     straddle a layer's neighbourhood cut-off - the rows on which the reference's torch.topk (src/data_encoding.py:98-99) may have chosen
     the other atom, the one known source of logit differences beyond 1e-4 against the reference (pesto_knn_tie_rows)."""
     import torch
+    pdb_filepaths = list(pdb_filepaths)
+    check_results_path(results_path, pdb_filepaths)      # no HDF5 library / colliding dataset names: raised now, not after the run
     n0 = model.config["em"]["N0"]
     dev = torch.device("cuda", model._gpu)
     results = {}
@@ -103,7 +138,11 @@ def apply_model(model, pdb_filepaths, write=True, suffix="_i{}.pdb", max_atoms=2
         finally:
             model.set_async_auto(was_async)
     if results_path is not None:
-        save_results(results, results_path)
+        try:
+            save_results(results, results_path)
+        except Exception as e:      # (checked up front; what is left is the file system) - the computed tables are not lost with it
+            e.results = results
+            raise
     return results
 
 

@@ -137,6 +137,11 @@ size_t ws_bytes(int64_t N, int64_t R) {
 
 int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
     const size_t N1 = (size_t)N + 1;
+    // the layer kernels address the per-atom arrays with 32-bit byte offsets behind a buffer resource (pesto_mfma_common.h): the largest,
+    // the centre records (REC_CEN floats per atom), must stay inside the 4 GB window
+    if (m->impl == 2 && N1 * REC_CEN * sizeof(float) > 0xfffffff0ull)
+        return fail(PESTO_ERR_INVALID, "N=%lld atoms in one launch exceed the layer kernels' limit of %lld (split the batch)", (long long)N,
+                    (long long)(0xfffffff0ull / (REC_CEN * sizeof(float)) - 1));
     int rc = 0;
     rc |= m->ids_s.ensure(N1 * KMAX * sizeof(int));
     rc |= m->geo.ensure(N1 * KMAX * sizeof(float4));
@@ -152,8 +157,7 @@ int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
         rc |= m->rec_nb.ensure(N1 * REC_NB * sizeof(float));
         rc |= m->rec_cen.ensure(N1 * REC_CEN * sizeof(float));
         rc |= m->rec_nb2.ensure(N1 * REC_A * sizeof(float));
-        // (also the edge kernel's operand stash: one 2 KB slot per tile of a wave's work item, 256 workgroups x 12 waves x 4 tiles)
-        rc |= m->zrec.ensure(std::max((size_t)N1 * REC_Z * sizeof(float), (size_t)EDGE_STASH_BYTES));
+        rc |= m->zrec.ensure((size_t)N1 * REC_Z * sizeof(float));
     }
     return rc ? fail(PESTO_ERR_NOMEM, "device workspace allocation failed for N=%lld R=%lld", (long long)N, (long long)R) : 0;
 }

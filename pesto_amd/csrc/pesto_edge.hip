@@ -17,7 +17,7 @@ struct alignas(16) EdgeWaveScratch {       // 16-byte multiple: the rows are rea
 };
 // offsets of the NEXT layer's prepare tables (the [U|A], G and nqm fragments / biases of LayerW): the finishing waves of the edge
 // kernel write that layer's centre / neighbour records right behind the state update (k_node16's prepare half, same arithmetic)
-struct PrepW { int32_t h_ua, h_gc, h_n0, n_b1s, n_bn0, n_bn1, n_bn2; };
+struct PrepW { int32_t h_ua, h_gc, h_n0, n_b1s, n_bn0, n_bn1, n_bn2, finite; };      // finite: store the centre records finite (the next layer is an nn = 8 layer)
 // XCH_FLOATS: tile-state exchange of the prepare phase (rendezvous mode): per 16-centre tile [q0 q1 p00 p01 p10 p11 p20 p21][fg 4][column][4];
 // the second tile of a twelve-wave workgroup holds 8 centres (24 per iteration) and is stored compactly: 2048 + 1024 floats
 constexpr int XCH_FLOATS = 3072;
@@ -78,8 +78,13 @@ __device__ __forceinline__ f32x4 l1_compute(const L1Ops& o, int fb, int g, float
     return h;
 }
 
-// per-tile addressing: centre record(s), neighbour record of this lane's edge, geometry
-struct TileCtx { const float *cenA, *cenB, *recj, *recj_p; float rx, ry, rz, d, bgA, bgB; };
+__device__ __forceinline__ int prod_piece(int lane) { return (lane & 3) ^ ((lane >> 5) << 1); }      // the 16-byte piece of its edge a PRODUCER lane loads (see to_mfma_lanes)
+// buffer resources of the arrays the item waves gather from (pesto_mfma_common.h: 32-bit per-lane offsets, uniform parts in SGPRs)
+struct EdgeBufs { __amdgpu_buffer_rsrc_t nb, cen, p; };
+// per-tile addressing: centre record(s), neighbour record of this lane's edge, geometry. The exact kernels use the pointers; the shipped
+// (hybrid) kernels byte offsets: sA / sB = the tile's centre record(s) (wave-uniform: c0 is), vp = this PRODUCER lane's 16 bytes of its
+// edge's A_j record (lane = 4 edge + piece, see prod_piece)
+struct TileCtx { const float *cenA, *cenB, *recj; int sA, sB, vp; float rx, ry, rz, d, bgA, bgB; };
 
 template <int NN, bool HY = false>
 __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1, const EdgeWaveScratch& ws,
@@ -87,14 +92,21 @@ __device__ __forceinline__ TileCtx tile_ctx(int t, int e, int g, int c0, int N1,
     TileCtx c;
     const int row = 16 * t + e;
     const int aA = NN == 8 ? 2 * t : (16 * t) / NN;
-    c.cenA = rec_cen + (size_t)ABL_CEN(min(c0 + aA, N1 - 1)) * REC_CEN;
-    c.cenB = rec_cen + (size_t)ABL_CEN(min(c0 + aA + 1, N1 - 1)) * REC_CEN;
+    if (HY) {
+        c.sA = ABL_CEN(min(c0 + aA, N1 - 1)) * (REC_CEN * 4);
+        c.sB = ABL_CEN(min(c0 + aA + 1, N1 - 1)) * (REC_CEN * 4);
+        c.vp = ABL_NB(ws.nb[16 * t + ((16 * g + e) >> 2)]) * (REC_A * 4) + 16 * prod_piece(16 * g + e);
+        c.cenA = c.cenB = c.recj = nullptr;
+    } else {
+        c.cenA = rec_cen + (size_t)ABL_CEN(min(c0 + aA, N1 - 1)) * REC_CEN;
+        c.cenB = rec_cen + (size_t)ABL_CEN(min(c0 + aA + 1, N1 - 1)) * REC_CEN;
+        c.recj = rec_nb + (size_t)ABL_NB(ws.nb[row]) * REC_NB;
+        c.sA = c.sB = c.vp = 0;
+    }
     c.rx = ws.geo[0][row]; c.ry = ws.geo[1][row]; c.rz = ws.geo[2][row]; c.d = ws.geo[3][row];
     const float bg = ws.geo[g == 3 ? 4 : g][row];      // B operand of the centre MFMA: (r_x, r_y, r_z, 1)[k = g], one LDS read
     c.bgA = (NN == 8 && e >= 8) ? 0.0f : bg;
     c.bgB = (NN == 8 && e >= 8) ? bg : 0.0f;
-    c.recj = rec_nb + (size_t)ABL_NB(ws.nb[row]) * (HY ? REC_A : REC_NB);
-    c.recj_p = rec_nb + (size_t)ABL_NB(ws.nb[16 * t + ((16 * g + e) >> 2)]) * (HY ? REC_A : REC_NB);
     return c;
 }
 
@@ -110,7 +122,6 @@ __device__ __forceinline__ float bperm(int src_byte, float v) {
 // Producer lanes hold the 16-byte pieces of an edge in swizzled order - lane 4 e + s holds piece s ^ (e >= 8 ? 2 : 0) - so that the 32
 // consumer lanes ds_bpermute serves together pull from 32 different banks (lanes l and l + 32 share one; unswizzled, edges e and e + 8
 // collided: 10 of the kernel's 14.8 % SQ_LDS_BANK_CONFLICT, profiles/r03_lds_conflict_ablation.txt). Pure data movement: same bits.
-__device__ __forceinline__ int prod_piece(int lane) { return (lane & 3) ^ ((lane >> 5) << 1); }                    // piece a producer lane loads
 __device__ __forceinline__ int cons_src(int lane) { return (4 * (lane & 15) + ((lane >> 4) ^ (((lane >> 3) & 1) << 1))) << 2; }   // byte address of the lane a consumer pulls
 __device__ __forceinline__ f32x4 to_mfma_lanes(f32x4 v, int lane) {
     const int src = cons_src(lane);
@@ -126,18 +137,18 @@ struct L1Raw { f32x4 x0, x1, y0, y1, z0, z1, a4[4]; float cA[4], cB[4]; };
 struct L1Head { f16x8 fh, fl; f32x4 acc[4]; float d; };
 
 template <int NN>
-__device__ __forceinline__ L1Raw l1_issue(int fb0, int t, int lane, const TileCtx& tc, const EdgeWaveScratch& ws,
-                                          const float* __restrict__ p_state) {
+__device__ __forceinline__ L1Raw l1_issue(int fb0, int t, int lane, const TileCtx& tc, const EdgeWaveScratch& ws, const EdgeBufs& B) {
     L1Raw r;
     const int rp = 16 * t + (lane >> 2);               // producer lane: edge rp, piece prod_piece(lane) (32 bytes of p_j, 16 of A_j)
-    const int pc = prod_piece(lane);
-    const float* pj = p_state + (size_t)ABL_NB(ws.nb[rp]) * 96 + 8 * pc;
-    r.x0 = ld4(pj); r.x1 = ld4(pj + 4); r.y0 = ld4(pj + 32); r.y1 = ld4(pj + 36); r.z0 = ld4(pj + 64); r.z1 = ld4(pj + 68);
+    const int pj = ABL_NB(ws.nb[rp]) * 384 + 32 * prod_piece(lane);      // byte offset of this lane's piece of p_j[x]; y, z: + 128, + 256
+    r.x0 = bufld4(B.p, pj); r.x1 = bufld4(B.p, pj + 16); r.y0 = bufld4(B.p, pj + 128); r.y1 = bufld4(B.p, pj + 144);
+    r.z0 = bufld4(B.p, pj + 256); r.z1 = bufld4(B.p, pj + 272);
+    const int l4 = lane * 4;
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
-        r.a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * pc);
-        r.cA[fb] = tc.cenA[(fb0 + fb) * 64 + lane];
-        r.cB[fb] = NN == 8 ? tc.cenB[(fb0 + fb) * 64 + lane] : 0.0f;
+        r.a4[fb] = bufld4(B.nb, tc.vp + (fb0 + fb) * 64);
+        r.cA[fb] = bufld1(B.cen, l4 + (fb0 + fb) * 256, tc.sA);
+        r.cB[fb] = NN == 8 ? bufld1(B.cen, l4 + (fb0 + fb) * 256, tc.sB) : 0.0f;
     }
     return r;
 }
@@ -177,14 +188,14 @@ __device__ __forceinline__ L1Head l1_head(const L1Raw& r, int t, int lane, const
 // loads it could overlap with: each of its dependent round trips is paid in full). Same values, same order: same bits as two passes.
 struct L1RawAC { f32x4 a4[4]; float cA[4], cB[4]; };
 template <int NN>
-__device__ __forceinline__ L1RawAC l1_issue_ac(int fb0, int lane, const TileCtx& tc) {
+__device__ __forceinline__ L1RawAC l1_issue_ac(int fb0, int lane, const TileCtx& tc, const EdgeBufs& B) {
     L1RawAC r;
-    const int pc = prod_piece(lane);
+    const int l4 = lane * 4;
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {
-        r.a4[fb] = ld4(tc.recj_p + (fb0 + fb) * 16 + 4 * pc);
-        r.cA[fb] = tc.cenA[(fb0 + fb) * 64 + lane];
-        r.cB[fb] = NN == 8 ? tc.cenB[(fb0 + fb) * 64 + lane] : 0.0f;
+        r.a4[fb] = bufld4(B.nb, tc.vp + (fb0 + fb) * 64);
+        r.cA[fb] = bufld1(B.cen, l4 + (fb0 + fb) * 256, tc.sA);
+        r.cB[fb] = NN == 8 ? bufld1(B.cen, l4 + (fb0 + fb) * 256, tc.sB) : 0.0f;
     }
     return r;
 }
@@ -226,18 +237,6 @@ __device__ __forceinline__ void l1_tail(L1Head& o, int fb0, int lane, int g, con
     }
 }
 
-__device__ __forceinline__ f32x4 bufld4(__amdgpu_buffer_rsrc_t r, int byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
-}
-__device__ __forceinline__ float bufld1(__amdgpu_buffer_rsrc_t r, int byte_off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
-}
-__device__ __forceinline__ float bufld1s(__amdgpu_buffer_rsrc_t r, int byte_off, int s_off) {      // s_off: wave-uniform (SGPR) part
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, s_off, 0));
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0xfffffffc, 0x00020000);
-}
 // v_permlane16_swap / v_permlane32_swap exchange rows (halves) BETWEEN two registers; with a copy of x in the second register the two
 // results are x and x[l ^ 16] (x[l ^ 32]) in some order, so a symmetric op needs no select. Inline asm (validated in
 // profiles/microbench/permlane_test.hip): the compiler's builtin returned the same register for both results here. Only called on values
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             const size_t src0 = (size_t)min(i0, N1 - 1) * KMAX + lane0 % NN;
             first_valid = i0 < N1 && lane0 < 16 * TI;
             first_nb = ids_s[src0];
-            first_geo = geo[src0];
+            first_geo = geo[src0];      // (plain loads: once per launch)
         }
     }
     {   // layer constants -> LDS (once per workgroup; workgroups are persistent over work items)
@@ -350,6 +349,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         ws0.geo[2][l0] = first_valid ? first_geo.z : 0.f; ws0.geo[3][l0] = first_valid ? first_geo.w : 0.f; ws0.geo[4][l0] = 1.0f;
     }
     __syncthreads();
+    const EdgeBufs eb{make_rsrc(rec_nb), make_rsrc(rec_cen), make_rsrc(p_state)};
     const float* w2f = sm.w + EL_W2F;
     const float* w3k = sm.w + EL_W3K;
     const float* w3v = sm.w + EL_W3V;
@@ -416,13 +416,15 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
           if (item_on && only_fl) item_on = rows_flagged(flags, work * A, A, N1, lane);
       }
       if (item_on) {
-        const int c0 = work * A;
+        // (wave-uniform, and scalar for the compiler on the shipped path: the centre-record offsets below are then SGPR arithmetic)
+        const int c0 = F16 ? __builtin_amdgcn_readfirstlane(work * A) : work * A;
         if (!(it_start == xcd * chunk && sub == 0)) {   // rows of this work item: lane = row (the first item's rows are staged already)
             const int a = lane / NN, c = lane % NN, i = c0 + a;
             const bool valid = i < N1 && lane < 16 * TI;
-            const size_t src = (size_t)min(i, N1 - 1) * KMAX + c;           // unconditional loads, select afterwards
-            const int nbv = ids_s[src];
-            const float4 gg = geo[src];
+            const unsigned src = (unsigned)min(i, N1 - 1) * KMAX + c;       // unconditional loads, select afterwards
+            const int nbv = __builtin_bit_cast(int, bufld1(make_rsrc(ids_s), (int)(src * 4u)));
+            const f32x4 gg4 = bufld4(make_rsrc(geo), (int)(src * 16u));
+            const float4 gg = float4{gg4[0], gg4[1], gg4[2], gg4[3]};
             ws.nb[lane] = valid ? nbv : 0;
             ws.geo[0][lane] = valid ? gg.x : 0.f; ws.geo[1][lane] = valid ? gg.y : 0.f; ws.geo[2][lane] = valid ? gg.z : 0.f;
             ws.geo[3][lane] = valid ? gg.w : 0.f; ws.geo[4][lane] = 1.0f;
@@ -518,8 +520,21 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     kacc += kacb;
                 }
                 // lane (e, g): kacc[0..2] = key of part g for edge row; logits against Q[0] (scalar) or Q[1] (vector)
-                const int aMine = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
-                const float* Qv = rec_cen + (size_t)ABL_CEN(min(c0 + aMine, N1 - 1)) * REC_CEN + 512 + (g == 0 ? 0 : 6);
+                float Qv[6];
+                if constexpr (F16) {      // six floats at byte 2048 (+ 24 for the vector queries) of the centre record: the centre as the scalar offset
+                    const int aT = NN == 8 ? 2 * t : (16 * t) / NN;
+                    const int sq = ABL_CEN(min(c0 + aT, N1 - 1)) * (REC_CEN * 4) + 512 * 4;
+                    int vq = g == 0 ? 0 : 24;
+                    if (NN == 8) vq += (e >> 3) * ((ABL_CEN(min(c0 + aT + 1, N1 - 1)) - ABL_CEN(min(c0 + aT, N1 - 1))) * (REC_CEN * 4));      // the tile's second centre
+                    const f32x4 qa = bufld4(eb.cen, vq, sq);
+                    const f32x2 qb = bufld2(eb.cen, vq + 16, sq);
+                    Qv[0] = qa[0]; Qv[1] = qa[1]; Qv[2] = qa[2]; Qv[3] = qa[3]; Qv[4] = qb[0]; Qv[5] = qb[1];
+                } else {
+                    const int aMine = NN == 8 ? 2 * t + (e >> 3) : (16 * t) / NN;
+                    const float* Qp = rec_cen + (size_t)ABL_CEN(min(c0 + aMine, N1 - 1)) * REC_CEN + 512 + (g == 0 ? 0 : 6);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) Qv[k] = Qp[k];
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float lgt = F16 ? Qv[3 * h] * kacc[0] + Qv[3 * h + 1] * kacc[1] + Qv[3 * h + 2] * kacc[2]      // t = log2(e) logit / sdk: Q' carries the scale
@@ -543,13 +558,13 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     if (t % TPC == 0) {
                         const int ic = ABL_CEN(min(c0 + (16 * t) / NN, N1 - 1));
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) pi3[c] = p_state[(size_t)ic * 96 + c * 32 + 16 * (g & 1) + e];
+                        for (int c = 0; c < 3; ++c) pi3[c] = bufld1(eb.p, (16 * (g & 1) + e) * 4 + c * 128, ic * 384);
                     }
-                    const L1Raw raw = l1_issue<NN>(0, t, lane, tcc, ws, p_state);
+                    const L1Raw raw = l1_issue<NN>(0, t, lane, tcc, ws, eb);
                     __builtin_amdgcn_sched_barrier(0);
                     L1Head hd = l1_head<NN>(raw, t, lane, tcc, ws);
                     __builtin_amdgcn_sched_barrier(0);
-                    const L1RawAC rac = l1_issue_ac<NN>(4, lane, tcc);      // the second half's A_j chunks / centre columns: in flight under the key networks
+                    const L1RawAC rac = l1_issue_ac<NN>(4, lane, tcc, eb);      // the second half's A_j chunks / centre columns: in flight under the key networks
                     const f16x8 keep_h = hd.fh, keep_l = hd.fl;
                     __builtin_amdgcn_sched_barrier(0);
                     float lgt[2];
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                         for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 2 * i2 + (esub & 1)]);
 #pragma unroll
-                        for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
+                        for (int i2 = 0; i2 < 4; ++i2) pv[i2] = bufld4(eb.p, nbj[i2] * 384 + 16 * quad);
                     }
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_sched_barrier(0);
@@ -628,7 +643,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                         for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)]);
 #pragma unroll
-                        for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
+                        for (int i2 = 0; i2 < 4; ++i2) pv[i2] = bufld4(eb.p, nbj[i2] * 384 + 16 * quad);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     f32x4 h2[4];
@@ -772,16 +787,16 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                     // software pipeline over the four tiles: the NEXT tile's gathers are issued as soon as this tile's raw loads
                     // have been consumed, and fly during this tile's MFMA / ELU / key-network work
                     TileCtx tcc = tile_ctx<NN, HY>(0, e, g, c0, N1, ws, rec_nb, rec_cen);
-                    L1Raw raw = l1_issue<NN>(0, 0, lane, tcc, ws, p_state);
+                    L1Raw raw = l1_issue<NN>(0, 0, lane, tcc, ws, eb);
 #pragma unroll 1
                     for (int t = 0; t < TI; ++t) {
                         if (SAT2 && t == TI / 2) { const float tmp = sat; sat = sat_b; sat_b = tmp; }      // the second centre's tiles start
                         L1Head hd = l1_head<NN>(raw, t, lane, tcc, ws);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (ONEP) { rac2 = l1_issue_ac<NN>(4, lane, tcc); pr_h = hd.fh; pr_l = hd.fl; }
+                        if (ONEP) { rac2 = l1_issue_ac<NN>(4, lane, tcc, eb); pr_h = hd.fh; pr_l = hd.fl; }
                         if (t < TI - 1) {
                             tcc = tile_ctx<NN, HY>(t + 1, e, g, c0, N1, ws, rec_nb, rec_cen);
-                            raw = l1_issue<NN>(0, t + 1, lane, tcc, ws, p_state);
+                            raw = l1_issue<NN>(0, t + 1, lane, tcc, ws, eb);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         f32x4 h1[4];
@@ -926,9 +941,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
             const TileCtx tc = PF ? tcn : tile_ctx<NN, HY>(t, e, g, c0, N1, ws, rec_nb, rec_cen);
             if (t % TPC == 0) {
                 if (EPI2) {
-                    const int ic = ABL_CEN(min(c0 + (NN == 8 ? 2 * t + (g >> 1) : (16 * t) / NN), N1 - 1));
+                    const int aT = NN == 8 ? 2 * t : (16 * t) / NN;
+                    const int ic = ABL_CEN(min(c0 + aT, N1 - 1));
+                    int vpi = (16 * (g & 1) + e) * 4;
+                    if (NN == 8) vpi += (g >> 1) * ((ABL_CEN(min(c0 + aT + 1, N1 - 1)) - ic) * 384);      // lane rows 2, 3: the tile's second centre
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) pi3[c] = p_state[(size_t)ic * 96 + c * 32 + 16 * (g & 1) + e];
+                    for (int c = 0; c < 3; ++c) pi3[c] = bufld1(eb.p, vpi + c * 128, ic * 384);
                 } else {
 #pragma unroll
                 for (int sel = 0; sel < (NN == 8 ? 2 : 1); ++sel) {
@@ -951,7 +969,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 2 * i2 + (esub & 1)]);
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
+                for (int i2 = 0; i2 < 4; ++i2) pv[i2] = bufld4(eb.p, nbj[i2] * 384 + 16 * quad);
             }
             f32x4 h1[4];
             if (PF) {
@@ -963,7 +981,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
                 if (ONEP) {
                     hd = l1_head_ac<NN>(rac2, pr_h, pr_l, lane, tc);
                 } else {
-                    const L1Raw raw = l1_issue<NN>(4, t, lane, tc, ws, p_state);
+                    const L1Raw raw = l1_issue<NN>(4, t, lane, tc, ws, eb);
                     __builtin_amdgcn_sched_barrier(0);
                     hd = l1_head<NN>(raw, t, lane, tc, ws);
                 }
@@ -1030,7 +1048,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) nbj[i2] = ABL_NB(ws.nb[16 * t + 8 + 2 * i2 + (esub & 1)]);
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) pv[i2] = ld4(p_state + (size_t)nbj[i2] * 96 + 4 * quad);
+                for (int i2 = 0; i2 < 4; ++i2) pv[i2] = bufld4(eb.p, nbj[i2] * 384 + 16 * quad);
             }
             if (PF && t < 3) {   // second half of the next tile's first-layer operands: in flight during the value MFMAs
 #pragma unroll
@@ -1376,7 +1394,7 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags,
                  const float* q_state, float* q_out, float* p_out, const LayerW* next, float* rec_nb_out, float* rec_cen_out, int mode) {
     PrepW pw{};
-    if (next) pw = PrepW{next->h_ua, next->h_gc, next->h_n0, next->n_b1s, next->n_bn0, next->n_bn1, next->n_bn2s};      // (the split path's queries carry the softmax scale)
+    if (next) pw = PrepW{next->h_ua, next->h_gc, next->h_n0, next->n_b1s, next->n_bn0, next->n_bn1, next->n_bn2s, next->nn == 8 ? 1 : 0};      // (the split path's queries carry the softmax scale)
     const EdgeIO io{ids_s, geo, rec_nb, rec_cen, p_state, Z, flags, q_state, q_out, p_out, pw, next ? rec_nb_out : nullptr, next ? rec_cen_out : nullptr};
     if (variant == 1) { launch_edge_exact(st, W, lw, N1, io, max_blocks); return; }
     if (q_out == nullptr || p_out == nullptr) { fprintf(stderr, "pesto: launch_edge: the shipped kernel needs the output half of the state pair\n"); abort(); }

@@ -54,8 +54,6 @@ void launch_layer_v1(hipStream_t st, const float* W, const LayerW& lw, int N1, c
 // structure's word when an activation left the f16 range (sat_probe)
 void launch_node(hipStream_t st, const float* W, const LayerW* finish, const LayerW* prep, int N1, float* q_state, float* p_state,
                  const float* Z, float* rec_nb, float* rec_cen, int variant, int* flags, Unpack2Args u2 = Unpack2Args());
-// Z of a fused launch (q_out != nullptr): the operand stash of the edge kernel - at least EDGE_STASH_BYTES, whatever N1 is
-constexpr size_t EDGE_STASH_BYTES = (size_t)256 * 12 * 4 * 2048;
 void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const int* ids_s, const float4* geo,
                  const float* rec_nb, const float* rec_cen, const float* p_state, float* Z, int max_blocks, int variant, int* flags,
                  const float* q_state = nullptr, float* q_out = nullptr, float* p_out = nullptr, const LayerW* next = nullptr,

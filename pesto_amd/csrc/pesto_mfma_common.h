@@ -226,6 +226,48 @@ __device__ __forceinline__ void mfma16_multi(const float* __restrict__ wf, int m
     for (int m = 0; m < NM; ++m) acc[m] = MFMA16(wl[m], xh, acc[m]);
 }
 
+// ---- buffer addressing: a 128-bit resource (base pointer in SGPRs, no bounds: the range is the whole 4 GB window behind the base) + a
+// 32-bit per-lane byte offset + a wave-uniform (SGPR) byte offset + a 12-bit immediate the compiler folds constant parts into. A global
+// load needs the full 64-bit address per lane (v_mad_i64_i32 / v_lshl_add_u64 / add_co pairs at 1.4 issue units each); here the per-lane
+// part is one 32-bit multiply-add and everything uniform costs scalar instructions only. Every array addressed this way is far below 4 GB
+// (the largest, the centre records, 2,112 B per atom: two million atoms).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xfffffffc, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bufld4(__amdgpu_buffer_rsrc_t r, int v_off, int s_off = 0) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v_off, s_off, 0));
+}
+__device__ __forceinline__ f16x8 bufld8h(__amdgpu_buffer_rsrc_t r, int v_off, int s_off = 0) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, v_off, s_off, 0));
+}
+__device__ __forceinline__ f32x2 bufld2(__amdgpu_buffer_rsrc_t r, int v_off, int s_off = 0) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, v_off, s_off, 0));
+}
+__device__ __forceinline__ float bufld1(__amdgpu_buffer_rsrc_t r, int v_off, int s_off = 0) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, v_off, s_off, 0));
+}
+__device__ __forceinline__ void bufst4(__amdgpu_buffer_rsrc_t r, int v_off, int s_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, v_off, s_off, 0);
+}
+// scalar base pointer + 32-bit per-lane byte offset (+ uniform byte offset): the compiler selects the SADDR form of global_load / global_store
+// (base in an SGPR pair, zero-extended VGPR offset, 13-bit immediate) - no 64-bit per-lane address arithmetic and no resource descriptor
+__device__ __forceinline__ f32x4 gld4(const void* base, unsigned v_off, unsigned s_off = 0) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + s_off + (size_t)v_off);
+}
+__device__ __forceinline__ void gst4(void* base, unsigned v_off, unsigned s_off, f32x4 v) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + s_off + (size_t)v_off) = v;
+}
+__device__ __forceinline__ void gst4_finite(void* base, unsigned v_off, unsigned s_off, f32x4 v) {      // see st4_finite
+    constexpr float M = 3.0e38f;
+    gst4(base, v_off, s_off, f32x4{__builtin_amdgcn_fmed3f(v[0], -M, M), __builtin_amdgcn_fmed3f(v[1], -M, M), __builtin_amdgcn_fmed3f(v[2], -M, M),
+                                   __builtin_amdgcn_fmed3f(v[3], -M, M)});
+}
+__device__ __forceinline__ void bufst4_finite(__amdgpu_buffer_rsrc_t r, int v_off, int s_off, f32x4 v) {      // see st4_finite
+    constexpr float M = 3.0e38f;
+    bufst4(r, v_off, s_off, f32x4{__builtin_amdgcn_fmed3f(v[0], -M, M), __builtin_amdgcn_fmed3f(v[1], -M, M), __builtin_amdgcn_fmed3f(v[2], -M, M),
+                                  __builtin_amdgcn_fmed3f(v[3], -M, M)});
+}
+
 // ---- cross-lane reductions on the VALU (DPP) instead of ds_bpermute round trips through the LDS crossbar
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {

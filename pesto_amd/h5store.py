@@ -3,7 +3,9 @@
 ``/`` in a key creating the groups on the way, exactly as h5py does.
 
 h5py is not a dependency of this package; the HDF5 C library is bound directly with ctypes (the 1.10 / 1.12 / 1.14 C API used here is
-the same: H5Fcreate / H5Dcreate2 / H5Dwrite / H5Dread / H5Lvisit). The library is looked for in ``$PESTO_HDF5_LIB``, the loader's
+the same: H5Fcreate / H5Dcreate2 / H5Dwrite / H5Dread; the link visitor is exported as H5Lvisit by 1.10 and as H5Lvisit2 / H5Lvisit1
+from 1.12 on, where H5Lvisit is a header macro - it is resolved lazily, by keys() only, so writing never depends on it. hid_t is
+bound as int64: the 1.10+ ABI). The library is looked for in ``$PESTO_HDF5_LIB``, the loader's
 search path and the usual prefixes (``/opt/conda/lib`` in the ROCm image). No library -> H5Unavailable with the places that were tried:
 the caller (apply.save_results) then has the .npz store, and says so - nothing is written silently in another format.
 
@@ -98,19 +100,29 @@ def load():
         "H5Tclose": (herr_t, [hid_t]),
         "H5Lexists": (ctypes.c_int, [hid_t, ctypes.c_char_p, hid_t]),
         "H5Ldelete": (herr_t, [hid_t, ctypes.c_char_p, hid_t]),
-        "H5Lvisit": (herr_t, [hid_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     }
     for name, (res, args) in sig.items():
         try:
             fn = getattr(lib, name)
         except AttributeError:
-            raise H5Unavailable(f"{lib._name} does not export {name}: not an HDF5 >= 1.8 C library")
+            raise H5Unavailable(f"{lib._name} does not export {name}: not an HDF5 >= 1.10 C library")
         fn.restype, fn.argtypes = res, args
     if lib.H5open() < 0:
         raise H5Unavailable(f"H5open failed in {lib._name}")
     lib.H5Eset_auto2(0, None, None)          # errors come back as negative return values -> H5Error here, not a stack dump on stderr
     _lib = lib
     return lib
+
+
+def _link_visitor(lib):
+    """The library's link visitor: H5Lvisit (an exported symbol up to 1.10), H5Lvisit2 or H5Lvisit1 (1.12+, where H5Lvisit is a macro).
+    The three differ in the info struct handed to the callback, which the callback here ignores. Resolved on first use (keys())."""
+    for name in ("H5Lvisit", "H5Lvisit2", "H5Lvisit1"):
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = herr_t, [hid_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            return fn
+    raise H5Unavailable(f"{lib._name} exports none of H5Lvisit / H5Lvisit2 / H5Lvisit1: the keys of a store cannot be listed")
 
 
 def available():
@@ -250,7 +262,7 @@ class H5Store:
             return 0
 
         cb = cb_t(visit)
-        _check(lib.H5Lvisit(self._id, H5_INDEX_NAME, H5_ITER_NATIVE, ctypes.cast(cb, ctypes.c_void_p), None), "H5Lvisit")
+        _check(_link_visitor(lib)(self._id, H5_INDEX_NAME, H5_ITER_NATIVE, ctypes.cast(cb, ctypes.c_void_p), None), "H5Lvisit")
         out = []
         for n in names:                        # links to groups are visited too: keep what opens as a dataset
             ds = lib.H5Dopen2(self._id, n.encode(), H5P_DEFAULT)

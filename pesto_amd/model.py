@@ -17,8 +17,10 @@ split MFMA and computes every STRUCTURE in which an activation left the f16 rang
 structures of the launch keep their logits: results do not depend on the grouping); "f16_split" never repeats (such a structure
 raises / returns NaN); "fp32" always uses the exact fp32 MFMA kernels (enum pesto_precision).
 ``async_auto`` (default False): with ROCm tensors and precision "auto", ``model(...)`` returns once the launch's range / input check
-has been read back (one 4-byte copy + a stream synchronisation), so ``z`` is final - what a drop-in caller that goes on with
-``torch.sigmoid(z)`` needs. True makes the call fully asynchronous: the check is made by the NEXT call on the model (or
+has been read back (a 4-byte copy queued in front of the pool kernels; the call waits for that copy, not for the stream): bad inputs
+have raised, an overflowed structure has been queued again on the exact kernels, and ``z`` is final in STREAM ORDER on torch's current
+stream - what a drop-in caller that goes on with ``torch.sigmoid(z)`` needs (torch keeps the tensors alive and ordered; a caller that
+reads ``z`` from another stream or overwrites an input from the host waits for the stream first). True makes the call fully asynchronous: the check is made by the NEXT call on the model (or
 ``synchronize()``), which may write the fp32 repeat into the same ``z``; until then an overflowed structure holds NaN.
 """
 import ctypes

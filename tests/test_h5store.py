@@ -112,3 +112,65 @@ def test_no_library_is_an_error_not_another_format(tmp_path, monkeypatch):
         monkeypatch.delenv("PESTO_HDF5_LIB")
         monkeypatch.setattr(h5store, "_lib", None)
         assert h5store.available()
+
+
+def test_link_visitor_is_resolved_lazily_under_any_of_its_exported_names(tmp_path, monkeypatch):
+    """HDF5 >= 1.12 exports H5Lvisit2 / H5Lvisit1 and keeps H5Lvisit as a header macro. A library without the plain name must
+    still load (writes never need the visitor) and list keys through whichever name it has; none of the three is an error of keys() only."""
+    lib = h5store.load()
+    real = h5store._link_visitor(lib)
+
+    class Proxy:      # the loaded library with a chosen set of visitor symbols
+        def __init__(self, have):
+            self._have, self._name = have, lib._name
+
+        def __getattr__(self, name):
+            if name in ("H5Lvisit", "H5Lvisit1", "H5Lvisit2"):
+                if name in self._have:
+                    return real
+                raise AttributeError(name)
+            return getattr(lib, name)
+
+    path = str(tmp_path / "v.h5")
+    for have in (("H5Lvisit",), ("H5Lvisit2", "H5Lvisit1"), ("H5Lvisit1",)):
+        monkeypatch.setattr(h5store, "_lib", Proxy(have))
+        with h5store.H5Store(path, "w") as hf:
+            hf["g/a"] = np.arange(3, dtype=np.float32)
+        with h5store.H5Store(path) as hf:
+            assert hf.keys() == ["g/a"]
+    monkeypatch.setattr(h5store, "_lib", Proxy(()))
+    with h5store.H5Store(path, "w") as hf:      # a write-only use does not depend on the visitor
+        hf["b"] = np.zeros(2, np.float32)
+    with h5store.H5Store(path) as hf:
+        assert np.array_equal(hf["b"], np.zeros(2, np.float32))
+        with pytest.raises(h5store.H5Unavailable, match="H5Lvisit2"):
+            hf.keys()
+    monkeypatch.setattr(h5store, "_lib", lib)
+
+
+def test_result_path_problems_are_found_before_the_work(tmp_path, monkeypatch):
+    """colliding dataset names ('/a.pdb' and 'a.pdb') and a missing HDF5 library are raised by the up-front check apply_model
+    makes (check_results_path), not in the middle of the final write; a failed write leaves no temporary file behind."""
+    from pesto_amd.apply import check_results_path, h5_dataset_names, save_results
+    tab = np.zeros((2, 5), np.float32)
+    with pytest.raises(ValueError, match="same HDF5 dataset name"):
+        check_results_path(str(tmp_path / "o.h5"), ["/a.pdb", "a.pdb"])
+    with pytest.raises(ValueError, match="same HDF5 dataset name"):
+        save_results({"/a.pdb": tab, "a.pdb": tab}, str(tmp_path / "o.h5"))
+    assert not os.path.exists(tmp_path / "o.h5") and not os.path.exists(tmp_path / "o.h5.tmp")
+    assert h5_dataset_names(["/x/a.pdb", "b"], {"b": "B/1"}) == {"/x/a.pdb": "x/a.pdb", "b": "B/1"}
+    check_results_path(str(tmp_path / "o.npz"), ["/a.pdb", "a.pdb"])      # the .npz form keeps the keys as they are
+    check_results_path(None, ["/a.pdb", "a.pdb"])
+    # a write that fails half way (a dataset name that is also a group of another) removes its temporary file
+    with pytest.raises(h5store.H5Error):
+        save_results({"a": tab, "b": tab}, str(tmp_path / "p.h5"), keys={"a": "g", "b": "g/x"})
+    assert not os.path.exists(tmp_path / "p.h5") and not os.path.exists(tmp_path / "p.h5.tmp")
+    monkeypatch.setattr(h5store, "_lib", None)
+    monkeypatch.setenv("PESTO_HDF5_LIB", str(tmp_path / "libhdf5_missing.so"))
+    try:
+        with pytest.raises(h5store.H5Unavailable):
+            check_results_path(str(tmp_path / "q.h5"), ["a"])
+    finally:
+        monkeypatch.delenv("PESTO_HDF5_LIB")
+        monkeypatch.setattr(h5store, "_lib", None)
+        assert h5store.available()
