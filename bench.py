@@ -2,23 +2,27 @@
 """bench.py - structures/s of the PeSTo forward pass (i_v4_1 architecture) on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON line on rank 0.
-  * one "step" = one pass of Model.forward over one collated batch of --batch synthetic structures
-    (N=3000 atoms, k=64, R=375 each; BASELINE.json configs[1]) with inputs already resident in HBM;
+  * one "step" = one call of the reference's own signature, Model.forward(X, ids_topk, q, M), over one collated batch of --batch
+    synthetic structures (N=3000 atoms, k=64, R=375 each; BASELINE.json configs[1]) with every input - the dense fp32 mask M
+    included - already resident in HBM (the mask is reduced to residue segments on the GPU inside the call);
   * --gpus N > 1 under plain `python` re-executes itself under torch.distributed.run with N ranks (one per GPU, RCCL);
     under the driver's own torch.distributed.run launch it reads RANK / LOCAL_RANK / WORLD_SIZE. Structures are independent,
     so each rank owns its own batch (weak scaling, no data-path collective); RCCL carries the barrier and the max-over-ranks time;
   * value = structures processed by all ranks / max-over-ranks wall time of the K timed steps.
 Extra objects in the same line:
   roofline        the dominant kernel (k_edge<64>), HIP-event timed inside the library on the launch stream: gather-counted
-                  algorithmic bytes per launch / duration against 8 TB/s, executed MFMA FLOP/s against the f16 pipe's peak,
-                  measured HBM-side bytes per launch from the committed PMC passes of this build (null when stale);
+                  algorithmic bytes per launch / duration against 8 TB/s (`frac`, SURVEY 8d definition A), the bytes that actually
+                  reached the fabric against the same peak (`hbm_actual_frac`), executed MFMA FLOP/s against the f16 pipe's peak, and
+                  what binds (`bound`: "issue" when neither exceeds one half - then `issue_floor_ratio` = launch time / the priced sum
+                  of the instructions the launch issues, at the `clock_GHz` the kernel held); the profile-derived keys come from the
+                  committed, hash-stamped PMC passes of this build (null when stale);
   cpu_baseline    the C oracle (a port of the reference CPU path) on this host's cores, bounded sample, plus the
                   reference-equivalent time rho x t_port (rho measured in the build container, profiles/r02_cpu_rho.json);
   config4_sharded BASELINE config 4 as a strong-scaling leg: a FIXED list of 64 structures with the pdbs_test size histogram
                   through pesto_amd.sharding.forward_sharded (nccl, device tensors in the gather), gathered z checked bitwise
                   against a world-1 run (--mode strong makes this leg the headline value);
-  value_exact_fp32, parity_max_abs: the same step on the exact fp32 MFMA kernels; the timed output against the committed
-                  reference golden of structure 0.
+  value_exact_fp32, exact_fp32, parity_max_abs: the same step on the exact fp32 MFMA kernels (with their fraction of the 157.3 TF
+                  fp32-MFMA peak per kernel); the timed output against the committed reference golden of structure 0.
 """
 import argparse
 import hashlib
@@ -70,6 +74,17 @@ def executed_mfma_flops(config, n1):
     return sum(edge_mfma_flops_per_atom(l["nn"]) + NODE_MFMA_FLOPS_PER_ATOM for l in config["sum"]) * n1
 
 
+def exact_edge_mfma_flops_per_atom(nn):
+    """FLOPs the matrix cores execute per centre atom in the EXACT fp32 edge kernel (k_edge<..., F16 = false>): per edge, layers 2 / 3 of
+    the three edge MLPs (eq 32x32 + ep 32x32 + ev 64x64; keys 64 -> 16 rows, values 64 x 64) and the centre terms (128 features x K = 4,
+    twice at nn = 8: two centres share a tile); the neighbour terms of layer 1 are VALU work there (full 2 KB records)."""
+    return nn * 2.0 * (6144.0 + 1024.0 + 4096.0 + 512.0 * (2 if nn == 8 else 1))
+
+
+# k_node (exact): finish (qpm 64-32-32-32, ppm 3 x 64-32) + records ([U|A] 64-256, [G|C] 3 x 32-256, nqm 64-32-32-16) per atom and layer
+EXACT_NODE_MFMA_FLOPS_PER_ATOM = 2.0 * (4096.0 + 6144.0 + 16384.0 + 24576.0 + 3584.0)
+
+
 def layer_gather_bytes_per_atom(nn):
     """Gather-counted bytes per atom per layer (definition A): 1,024 + 532*n."""
     return 1024.0 + 532.0 * nn
@@ -87,12 +102,18 @@ def per_nn_table(config, kern, n1, traffic_file):
         b_a = layer_gather_bytes_per_atom(nn) * n1
         row = {"avg_launch_ms": k["avg_launch_ms"], "launches_per_forward": k["launches_per_forward"],
                "frac_def_A": b_a / (k["avg_launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-               "rocprof_avg_launch_ms": None, "frac_def_A_rocprof": None, "traffic": None, "traffic_over_compulsory": None}
+               "rocprof_avg_launch_ms": None, "frac_def_A_rocprof": None, "traffic": None, "traffic_over_compulsory": None,
+               "hbm_actual_frac": None, "clock_GHz": None, "issue_floor_ratio": None}
         if traffic_file:
             hit = [v for kk, v in traffic_file["kernels"].items() if f"k_edge<{nn}," in kk]
             if hit:
                 row["traffic"] = 2.0 * hit[0]["fetch_bytes_per_dispatch_raw"] + hit[0]["write_bytes_per_dispatch"]
                 row["traffic_over_compulsory"] = row["traffic"] / ((1024.0 + 4.0 * nn) * n1)
+                row["hbm_actual_frac"] = row["traffic"] / (k["avg_launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+            fl = traffic_file.get("issue_floor", {}).get("per_nn", {}).get(str(nn))
+            if fl:      # (profiles/issue_floor.py: the clock of the profiled dispatch; the ratio re-taken with THIS run's launch time)
+                row["clock_GHz"] = fl["clock_GHz"]
+                row["issue_floor_ratio"] = k["avg_launch_ms"] * 1e3 / fl["predicted_us"]
             tr = [v for kk, v in traffic_file.get("rocprof_kernel_trace", {}).get("kernels", {}).items() if f"k_edge<{nn}," in kk]
             if tr:
                 row["rocprof_avg_launch_ms"] = tr[0]["avg_ns"] * 1e-6
@@ -481,8 +502,15 @@ def run(args, stage):
     qd = torch.from_numpy(q).to(dev)
     road = torch.from_numpy(roa).to(dev)
     n_atoms_total = X.shape[0]
+    # the dense residue mask of the reference's call (collate_batch_features: block-diagonal float [sum N, sum R], src/dataset.py:101,110),
+    # resident in HBM like the other inputs (callers pass M.float().to(device), apply_model.ipynb:155)
+    Md = torch.zeros((n_atoms_total, R), dtype=torch.float32, device=dev)
+    Md[torch.arange(n_atoms_total, device=dev), road.long()] = 1.0
 
-    def step():
+    def step():      # the reference's own signature (model/model.py:32): the mask is reduced to segments on the GPU inside the call
+        return model(Xd, idsd, qd, Md)
+
+    def step_segments():      # the same forward with the mask pre-reduced by the caller (an extra key of the line)
         return model.forward_segments(Xd, idsd, qd, road, R)
 
     def barrier():
@@ -546,6 +574,33 @@ def run(args, stage):
         model.set_precision(args.precision)
         exact = {"value": max(3, min(args.steps, 10)) * args.batch * world / el32,
                  "max_abs_vs_timed_output": float((z32 - z).abs().max().item())}
+        # per-kernel launch times of the exact path (HIP events between consecutive launches) against the fp32 MFMA peak
+        model.set_precision("fp32")
+        model.set_timing(True, per_kernel=True)
+        pk32 = []
+        for _ in range(3):
+            step_segments()
+            torch.cuda.synchronize()
+            pk32.append(model.get_kernel_timing())
+        model.set_timing(False)
+        model.set_precision(args.precision)
+        n1_ = X.shape[0] + 1
+        ex_k = {}
+        for name in pk32[0]:
+            n_l = pk32[0][name][1]
+            if not n_l:
+                continue
+            ms_ = float(np.median([pk[name][0] for pk in pk32])) / n_l
+            fl_ = EXACT_NODE_MFMA_FLOPS_PER_ATOM * n1_ * (len(config["sum"]) / n_l) if name == "node" else exact_edge_mfma_flops_per_atom(int(name[7:])) * n1_
+            ex_k[name] = {"launches_per_forward": n_l, "avg_launch_ms": ms_, "executed_mfma_TFLOPs": fl_ / (ms_ * 1e-3) / 1e12,
+                          "frac_of_fp32_mfma_peak": fl_ / (ms_ * 1e-3) / 1e12 / PEAK_F32_TFLOPS}
+        fl_all = sum(exact_edge_mfma_flops_per_atom(l["nn"]) + EXACT_NODE_MFMA_FLOPS_PER_ATOM for l in config["sum"]) * n1_
+        t_all32 = sum(v["avg_launch_ms"] * v["launches_per_forward"] for v in ex_k.values()) * 1e-3
+        exact["kernels"] = ex_k
+        exact["frac_of_fp32_mfma_peak"] = fl_all / t_all32 / 1e12 / PEAK_F32_TFLOPS if t_all32 > 0 else None
+        exact["peak_TFLOPs"] = PEAK_F32_TFLOPS
+        exact["definition"] = ("FLOPs the matrix cores execute in k_edge<..., F16 = false> (layers 2 / 3 of the edge MLPs and the centre terms; the "
+                               "neighbour terms of layer 1 are VALU work there) and k_node, / time by HIP events / the 157.3 TF fp32 MFMA peak")
 
     # ---- roofline leg: HIP events around the state-update launches, on the stream they run on
     model.set_timing(True)
@@ -603,20 +658,32 @@ def run(args, stage):
             hit = [v for k, v in traffic_file["kernels"].items() if f"k_edge<{nn_max}," in k]
             if hit:
                 traffic = 2.0 * hit[0]["fetch_bytes_per_dispatch_raw"] + hit[0]["write_bytes_per_dispatch"]
-        bound = "hbm" if hbm_frac >= mfma_frac else "mfma"
         per_nn, frac_rocprof = per_nn_table(config, kern, n1, traffic_file)
+        dom_row = per_nn.get(str(nn_max), {})
+        hbm_actual = dom_row.get("hbm_actual_frac")
+        # what binds: the matrix pipe or the fabric only when one of them is at least half used. The achieved / peak / frac keys keep SURVEY
+        # 8d's definition (A) - gather-counted bytes against the HBM peak, a cache-bandwidth figure - whatever `bound` says; with neither
+        # pipe half used the kernel is bound by the NUMBER of instructions it issues (issue_floor_ratio prices them)
+        bound = "mfma" if mfma_frac >= 0.5 else ("hbm" if (hbm_actual if hbm_actual is not None else hbm_frac) >= 0.5 else "issue")
         roofline = {
             "kernel": f"k_edge<{nn_max}> = one whole state-update layer: edges, attention, the layer's output MLPs (finish phase) and the next "
                       f"layer's per-atom records (prepare phase) (dominant: {dom['avg_launch_ms'] * dom['launches_per_forward'] / t_all:.0%} of the layer time)",
             "bound": bound,
-            "achieved": b_a / t_s / 1e9 if bound == "hbm" else f_exec / t_s / 1e12,
-            "peak": PEAK_HBM_GBS if bound == "hbm" else PEAK_F16_TFLOPS,
-            "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-            "frac": max(hbm_frac, mfma_frac),
+            "bound_note": "issue = instruction issue: the fabric sees hbm_actual_frac of its peak, the matrix cores run at mfma.frac of theirs; "
+                          "achieved / peak / frac are SURVEY 8d's definition (A) (algorithmic gather-counted bytes / launch time / 8 TB/s)",
+            "achieved": f_exec / t_s / 1e12 if bound == "mfma" else b_a / t_s / 1e9,
+            "peak": PEAK_F16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": mfma_frac if bound == "mfma" else hbm_frac,
+            # traffic / launch time / 8 TB/s: what the fabric actually carried (committed PMC passes of this build)
+            "hbm_actual_frac": hbm_actual,
+            # launch time / (dynamic instruction classes of the launch x the micro-benchmark price list at the clock of the profiled dispatch)
+            "issue_floor_ratio": dom_row.get("issue_floor_ratio"),
+            "clock_GHz": dom_row.get("clock_GHz"),
             # the same fraction from the COMMITTED rocprofv3 kernel trace (average duration of this kernel in the hash-stamped profile
             # of this build, profiles/traffic_*.json; the profiler adds ~5 % to a launch and the trace may come from another box of
             # the pool): null when the committed profile was taken on other kernel sources
-            "frac_rocprof": frac_rocprof.get(nn_max) if bound == "hbm" else None,
+            "frac_rocprof": frac_rocprof.get(nn_max) if bound != "mfma" else None,
             "traffic": traffic,
             # SURVEY 8d definition (B): compulsory bytes with a perfect cache - own state read + written (1,024 B) and 4 B of ids per edge
             "traffic_over_compulsory": (traffic / ((1024.0 + 4.0 * nn_max) * n1)) if traffic else None,
@@ -663,25 +730,22 @@ def run(args, stage):
                        "structures_per_s_from_median": args.batch / float(np.median(dt)) * 1e3,
                        "how": "HIP events between consecutive steps on torch's current stream (the stream the kernels are launched on)"}
 
-    # ---- the reference's own call: Model.forward(X, ids_topk, q, M) with the DENSE residue mask on the device (model/model.py:32);
-    # the mask is reduced to segments by k_mask_to_segments inside the call (the headline step hands the segments over directly)
-    ref_sig = None
+    # ---- the same forward with the mask pre-reduced by the caller (forward_segments: res_of_atom instead of M); until round 5 the headline
+    seg_call = None
     if not args.no_extras:
-        Md = torch.zeros((n_atoms_total, R), dtype=torch.float32, device=dev)
-        Md[torch.arange(n_atoms_total, device=dev), road.long()] = 1.0
         n_sig = max(5, min(args.steps, 20))
         for _ in range(2):
-            zs = model(Xd, idsd, qd, Md)
+            zs = step_segments()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(n_sig):
-            zs = model(Xd, idsd, qd, Md)
+            zs = step_segments()
         torch.cuda.synchronize()
         t_sig = (time.perf_counter() - t1) / n_sig
-        ref_sig = {"call": "Model.forward(X, ids_topk, q, M): dense fp32 mask M [N, R] resident in HBM, reduced on the GPU by k_mask_to_segments",
-                   "mask_bytes": int(n_atoms_total) * int(R) * 4, "steps": n_sig, "ms_per_step": t_sig * 1e3,
-                   "structures_per_s": args.batch / t_sig, "bitwise_equal_to_segment_call": bool(torch.equal(zs, z))}
-        del Md
+        seg_call = {"call": "Model.forward_segments(X, ids_topk, q, res_of_atom, R): the dense mask reduced by the caller (not in the timed region)",
+                    "mask_bytes_not_read": int(n_atoms_total) * int(R) * 4, "steps": n_sig, "ms_per_step": t_sig * 1e3,
+                    "structures_per_s": args.batch / t_sig, "bitwise_equal_to_the_headline_call": bool(torch.equal(zs, z)),
+                    "mask_pass_ms_per_step": elapsed / args.steps * 1e3 - t_sig * 1e3}
 
     # ---- side measurement: batch-1 latency (ms per structure when structures arrive one at a time)
     lat_ms = lat_detail = None
@@ -742,7 +806,7 @@ def run(args, stage):
                         "why": "untimed steps in front of the W warm-up steps: the host-side set-up leaves the GPU idle, and an idle MI355X needs "
                                "~30 ms of work to reach its steady clocks"},
             "long_sample": long_sample,
-            "reference_signature": ref_sig,
+            "segment_call": seg_call,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -750,9 +814,11 @@ def run(args, stage):
                       "f16_split": "f32 (3xf16-split MFMA, fp32 accumulate)", "fp32": "f32 (exact fp32 MFMA)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": (cfg4["workload"] if strong else
-                                    f"{args.config} forward ({len(config['sum'])} state-update layers), synthetic cloud "
+                                    f"{args.config} Model.forward(X, ids_topk, q, M) ({len(config['sum'])} state-update layers), synthetic cloud "
                                     f"N={args.atoms} atoms k=64 R={R // args.batch} per structure, {args.batch} structures "
-                                    f"collated per step per GPU, atom order {args.order}, inputs resident in HBM, {wdesc}"),
+                                    f"collated per step per GPU (dense fp32 mask M [{n_atoms_total}, {R}] = {n_atoms_total * R * 4 / 1e6:.0f} MB read and "
+                                    f"reduced on the GPU inside every step), atom order {args.order}, inputs resident in HBM, {wdesc}"),
+                       "call": "Model.forward(X, ids_topk, q, M)", "mask_bytes_per_step": int(n_atoms_total) * int(R) * 4,
                        "atoms_per_step_per_gpu": int(n_atoms_total), "structures_per_step_per_gpu": args.batch,
                        "precision": args.precision, "fp32_reruns_in_timed_region": status["n_fp32_rerun"],
                        "sharding": f"{world} rank(s), independent structures per rank, no data-path collective"},
@@ -762,6 +828,7 @@ def run(args, stage):
             "per_rank": None if rank_times is None else [{"rank": r_, "seconds": t_, "value": args.steps * args.batch / t_} for r_, t_ in enumerate(rank_times)],
             "rank_time_max_over_min": None if rank_times is None else max(rank_times) / min(rank_times),
             "value_exact_fp32": exact["value"] if exact else None,
+            "exact_fp32": exact,
             "exact_fp32_max_abs_vs_timed_output": exact["max_abs_vs_timed_output"] if exact else None,
             "parity_max_abs": parity,
             "parity_note": "max |z - reference golden| over structure 0 of the LAST timed step (tests/golden/fwd_i_v4_1_stacked_synth3000.npz, "

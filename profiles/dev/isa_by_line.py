@@ -1,6 +1,6 @@
 """Static instruction counts of ONE kernel of an AMDGPU listing compiled with -gline-tables-only, attributed to source lines:
   hipcc ... -gline-tables-only -S pesto_edge.hip -o /tmp/layer_g.s
-  python profiles/dev/isa_by_line.py /tmp/layer_g.s 'k_edgeILi8ELi12ELb0ELb1ELb1ELi1ELb1ELi8ELb0EE' [first:last[:name] ...]
+  python profiles/dev/isa_by_line.py /tmp/layer_g.s 'k_edgeILi8ELi12ELb1ELi1ELi8EE' [first:last[:name] ...]
 Without ranges: one row per source line of file 0 (the .hip file) with >= 4 instructions; with ranges: one row per range.
 (.loc gives the innermost inlined location: split8 / elu4s / row_reduce bodies show up under their own lines.)"""
 import collections

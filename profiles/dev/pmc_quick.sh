@@ -10,7 +10,7 @@ import csv, glob, re, sys, collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
 for f in glob.glob(sys.argv[1]+"/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        m=re.search(r"k_edge<(\d+), (\d+)[^>]*?(\d+), (false|true)>", row["Kernel_Name"])
+        m=re.search(r"k_edge<(\d+), (\d+), (?:true|false), \d+, (\d+)()>", row["Kernel_Name"])
         if not m: continue
         k=f"k_edge<{m.group(1)},NE={m.group(3)}>"
         agg[k][row["Counter_Name"]]+=float(row["Counter_Value"]); cnt[(k,row["Counter_Name"])]+=1

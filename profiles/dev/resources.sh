@@ -12,7 +12,7 @@ for l in sys.stdin:
     m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", l); sc = m.group(1) if m else sc
     m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", l)
     if m:
-        t = re.search(r"k_edgeILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELb(\d)ELi(\d+)ELb(\d)", name)
-        short = ("k_edge<%s,%s,%s,%s,%s,%s,%s,%s,%s>" % t.groups()) if t else name[:40]
+        t = re.search(r"k_edgeILi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)E", name)
+        short = ("k_edge<%s,%s,%s,%s,%s>" % t.groups()) if t else name[:40]
         print(f"{short:44s} VGPR {vg:>4s} AGPR {ag:>3s} scratch {sc:>4s} occ {m.group(1)}")
 '

@@ -3,7 +3,9 @@
 (rocprofv3 --pmc, profiles/pmc_classes.sh) x the issue prices of profiles/microbench/r03_valu_cost.txt / r03_shadow.txt, at the clock
 the kernel actually ran at (GRBM_GUI_ACTIVE / 8 XCDs / duration of the same dispatch), against the measured launch time.
 
-    python profiles/issue_floor.py gpurun_out/<tag>/classes [bench.json]  ->  markdown table on stdout
+    python profiles/issue_floor.py gpurun_out/<tag>/classes [bench.json [traffic.json]]  ->  markdown table on stdout; with a third
+    argument the per-kernel clock, predicted and measured launch times and their ratio are also written INTO that hash-stamped file
+    (key "issue_floor"), which is where bench.py's roofline.issue_floor_ratio / roofline.clock_GHz come from
 
 Model (profiles/microbench/README.md): on gfx950 the VALU and MFMA instructions of the waves of one SIMD issue one after the
 other - a v_mfma_f32_16x16x32_f16 hides nothing (20.8 cycles with or without VALU around it, r03_shadow.txt) - so a SIMD's time is the SUM
@@ -39,7 +41,7 @@ def load(root):
     dur = collections.defaultdict(list)
     for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            m = re.search(r"k_edge<(\d+), (\d+)[^>]*?(\d+), (false|true)>", row["Kernel_Name"])
+            m = re.search(r"k_edge<(\d+), (\d+), (?:true|false), \d+, (\d+)()>", row["Kernel_Name"])
             if not m:
                 continue
             k = (int(m.group(1)), int(m.group(3)))
@@ -62,6 +64,7 @@ def main():
         for nn in (8, 16, 32, 64):
             meas[nn] = b["whole_forward"]["kernels"][f"edge_nn{nn}"]["avg_launch_ms"] * 1e3
     n1 = 24001
+    summary = {}
     print("| kernel | tiles | VALU / tile | MFMA f16 + f32 / tile | issue units / tile (VALU + MFMA) | clock under the kernel | predicted launch | measured (HIP events, same call) | measured / predicted |")
     print("|---|---|---|---|---|---|---|---|---|")
     for (nn, ne) in sorted(res):
@@ -74,9 +77,17 @@ def main():
         units = valu_units + mfma_units
         t_pred = units / N_SIMD * UNIT_CYCLES / (d["clock_GHz"] * 1e3)          # us
         t_meas = meas.get(nn)
+        summary[str(nn)] = {"item_waves": ne, "clock_GHz": d["clock_GHz"], "issue_units_per_tile": units / tiles, "predicted_us": t_pred,
+                            "measured_us": t_meas, "measured_over_predicted": (t_meas / t_pred) if t_meas else None}
         print(f"| `k_edge<{nn}>` ({ne} item waves) | {tiles:,.0f} | {d['SQ_INSTS_VALU'] / tiles:.0f} | {d['SQ_INSTS_VALU_MFMA_F16'] / tiles:.1f} + {d['SQ_INSTS_VALU_MFMA_F32'] / tiles:.1f} | "
               f"{units / tiles:,.0f} ({valu_units / tiles:,.0f} + {mfma_units / tiles:,.0f}) | {d['clock_GHz']:.2f} GHz | {t_pred:.1f} us | "
               + (f"{t_meas:.1f} us | {t_meas / t_pred:.2f} |" if t_meas else "- | - |"))
+    if len(sys.argv) > 3:
+        tf = json.load(open(sys.argv[3]))
+        tf["issue_floor"] = {"per_nn": summary, "how": "profiles/issue_floor.py: dynamic instruction classes of a launch (rocprofv3 --pmc, profiles/pmc_classes.sh) x "
+                             "the micro-benchmark price list, at the clock of the same dispatch (GRBM_GUI_ACTIVE / 8 XCDs / duration), against "
+                             "the launch time by HIP events in the same gpurun call"}
+        json.dump(tf, open(sys.argv[3], "w"), indent=1)
     print()
     for (nn, ne) in sorted(res):
         d = res[(nn, ne)]

@@ -18,7 +18,26 @@ cd $R
 GRAFT_REPO_ROOT=$R bash profiles/pmc_classes.sh $TAG > $R/gpurun_out/$TAG/pmc_classes.log 2>&1
 cd $R
 cp gpurun_out/$TAG/traffic.json profiles/traffic_i_v4_1_n3000_b8.json
-timeout 600 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
-python profiles/issue_floor.py gpurun_out/$TAG/classes gpurun_out/$TAG/bench.json > gpurun_out/$TAG/issue_floor_table.md 2>&1
+# the exact fp32 kernels (PESTO_PRECISION_FP32, what "auto" repeats a structure on): their kernel trace goes into the same stamped file
+( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/trace_fp32 -o trace --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --no-latency --no-extras --precision fp32 > $R/gpurun_out/$TAG/trace_fp32.log 2>&1 )
+cp $(find gpurun_out/$TAG/trace_fp32 -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/kernel_stats_fp32.csv 2>/dev/null
+python - gpurun_out/$TAG/kernel_stats_fp32.csv gpurun_out/$TAG/traffic.json <<'PY'
+import csv, json, re, sys
+t = json.load(open(sys.argv[2])); tr = {}
+try:
+    for row in csv.DictReader(open(sys.argv[1])):
+        m = re.search(r"(k_edge<[^>]*>|k_node\b)", row["Name"])
+        if m and ("false" in m.group(1) or m.group(1) == "k_node"):
+            tr[m.group(1).replace(" ", "")] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
+except OSError:
+    pass
+t["rocprof_kernel_trace_fp32"] = {"kernels": tr, "how": "rocprofv3 --kernel-trace --stats of python bench.py --steps 5 --warmup 2 --precision fp32 (same gpurun call)"}
+json.dump(t, open(sys.argv[2], "w"), indent=1)
+PY
+# first bench line (un-stamped issue-floor keys) -> the floor table -> written into the stamped file -> the bench line the round commits
+timeout 600 python bench.py --no-extras --cpu-budget 0 --no-latency > gpurun_out/$TAG/bench_pre.json 2> gpurun_out/$TAG/bench_pre.err
+python profiles/issue_floor.py gpurun_out/$TAG/classes gpurun_out/$TAG/bench_pre.json gpurun_out/$TAG/traffic.json > gpurun_out/$TAG/issue_floor_table.md 2>&1
+cp gpurun_out/$TAG/traffic.json profiles/traffic_i_v4_1_n3000_b8.json
+timeout 900 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 tail -c 600 gpurun_out/$TAG/pmc_per_nn.txt
 head -c 1500 gpurun_out/$TAG/bench.json

@@ -45,12 +45,20 @@ def test_per_nn_table_and_rocprof_fraction():
     assert sorted(table) == ["16", "32", "64", "8"] and frac_rp == {}
     assert abs(table["64"]["frac_def_A"] - 0.389) < 1e-3 and abs(table["8"]["frac_def_A"] - 0.253) < 1e-3      # the round-3 verdict's table
     assert all(table[k]["frac_def_A_rocprof"] is None and table[k]["traffic"] is None for k in table)
-    tf = {"kernels": {"k_edge<64,12,false,true,true,4,true,12,false>": {"fetch_bytes_per_dispatch_raw": 80.0e6, "write_bytes_per_dispatch": 72.0e6}},
-          "rocprof_kernel_trace": {"kernels": {"k_edge<64,12,false,true,true,4,true,12,false>": {"calls": 136, "avg_ns": 300400.0}}}}
+    tf = {"kernels": {"k_edge<64,12,true,4,12>": {"fetch_bytes_per_dispatch_raw": 80.0e6, "write_bytes_per_dispatch": 72.0e6}},
+          "rocprof_kernel_trace": {"kernels": {"k_edge<64,12,true,4,12>": {"calls": 136, "avg_ns": 300400.0}}}}
     table, frac_rp = bench.per_nn_table(cfg, kern, n1, tf)
     assert abs(frac_rp[64] - 0.350) < 1e-3 and abs(table["64"]["rocprof_avg_launch_ms"] - 0.3004) < 1e-6
     assert abs(table["64"]["traffic"] - 232.0e6) < 1 and abs(table["64"]["traffic_over_compulsory"] - 232.0e6 / (1280.0 * n1)) < 1e-9
     assert table["8"]["frac_def_A_rocprof"] is None
+    # what the fabric actually carried, the clock under the kernel and the issue-floor ratio ride in the same stamped file
+    assert abs(table["64"]["hbm_actual_frac"] - 232.0e6 / 0.2705e-3 / 8e12) < 1e-9 and table["64"]["clock_GHz"] is None
+    tf["issue_floor"] = {"per_nn": {"64": {"clock_GHz": 2.16, "predicted_us": 241.8, "measured_us": 243.6, "measured_over_predicted": 1.007}}}
+    table, _ = bench.per_nn_table(cfg, kern, n1, tf)
+    assert table["64"]["clock_GHz"] == 2.16 and abs(table["64"]["issue_floor_ratio"] - 270.5 / 241.8) < 1e-9 and table["8"]["issue_floor_ratio"] is None
     src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"hbm_actual_frac"', '"issue_floor_ratio"', '"clock_GHz"', '"frac_of_fp32_mfma_peak"', '"bound_note"', '"segment_call"', '"call": "Model.forward(X, ids_topk, q, M)"'):
+        assert key in src, key
+    assert 'else "issue"' in src      # neither pipe half used: the line says instruction issue binds, not hbm
     assert '"frac_rocprof"' in src and '"per_nn"' in src and "speedup_vs_reference_equivalent_cpu_estimate" in src
     assert 'out["speedup_vs_reference_equivalent_cpu"]' not in src

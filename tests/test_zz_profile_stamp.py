@@ -32,3 +32,17 @@ def test_stamp_carries_the_kernel_trace_of_every_layer_kernel():
         hit = [v for k, v in tr.items() if f"k_edge<{nn}," in k]
         assert hit and hit[0]["calls"] >= 8 and hit[0]["avg_ns"] > 0, nn
         assert any(f"k_edge<{nn}," in k for k in t["kernels"]), nn
+
+
+def test_stamp_carries_the_issue_floor_the_clock_and_the_exact_kernels():
+    """roofline.issue_floor_ratio / clock_GHz (per layer kernel) and the exact fp32 kernels' trace come from the same
+    stamped file, so they are non-null in the bench line exactly when the stamp matches the tree."""
+    t = _stamp()
+    per = t["issue_floor"]["per_nn"]
+    for nn in ("8", "16", "32", "64"):
+        assert 1.5 < per[nn]["clock_GHz"] < 3.0 and per[nn]["predicted_us"] > 0 and per[nn]["measured_over_predicted"] > 0.8, nn
+    fp32 = t["rocprof_kernel_trace_fp32"]["kernels"]
+    assert any("k_edge<64,4,false" in k for k in fp32) and all(v["avg_ns"] > 0 for v in fp32.values())
+    table, _ = bench.per_nn_table({"sum": [{"nn": 64}]}, {"edge_nn64": {"launches_per_forward": 8, "avg_launch_ms": 0.25}}, 24001, t)
+    row = table["64"]
+    assert row["hbm_actual_frac"] is not None and row["issue_floor_ratio"] is not None and row["clock_GHz"] is not None
