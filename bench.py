@@ -408,6 +408,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="testing only: every rank uses GPU 0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
+    ap.add_argument("--no-numa-bind", action="store_true", help="do not pin the rank to the CPUs of its GPU's NUMA node")
     ap.add_argument("--edge-mode", type=int, default=0, help="developer: pesto_debug_edge_mode (0 = per launch, 1 rendezvous, 2 node waves)")
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="atom numbering of the synthetic clouds: generation order, or along a Z-order curve")
@@ -458,6 +459,10 @@ def run(args, stage):
     gpu = 0 if args.same_gpu else local_rank
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
+    # one rank per GPU: pin the rank to the CPUs of its GPU's NUMA node (host packing + H2D of the config-4 legs; no-op where sysfs
+    # gives no node - reported per rank in ranks.devices)
+    from pesto_amd import sharding as _shn
+    numa_info = _shn.bind_rank_to_numa(dev) if not args.no_numa_bind else {"numa_node": None, "cpus_allowed": None, "cpu_list_head": None, "bound": False, "why": "--no-numa-bind"}
     dist = None
     stage[0] = "process group init (torch.distributed, backend %s)" % args.backend
     if world > 1:
@@ -490,7 +495,7 @@ def run(args, stage):
     wb = _sh.broadcast_weights(model, sd if rank == 0 else None, src=0, device=dev)
     if wdesc is None:
         wdesc = "weights received from rank 0"
-    ranks_info = _sh.describe_ranks(dev)
+    ranks_info = _sh.describe_ranks(dev, numa=numa_info)
     if args.edge_mode:
         model.debug_edge_mode(args.edge_mode)
 

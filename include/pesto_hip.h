@@ -104,6 +104,11 @@ int pesto_destroy(pesto_model* m);
  * of launch sequences run so far and how many STRUCTURES AUTO computed again on the fp32 kernels */
 int pesto_set_precision(pesto_model* m, int32_t precision);
 int pesto_get_status(const pesto_model* m, int32_t* precision, int64_t* n_forward, int64_t* n_fp32_rerun);
+/* PESTO_PRECISION_AUTO's bill: structures (members of a batch, trajectory frames, collated calls) forwarded on the split kernels and how
+ * many of them were computed again on the exact fp32 kernels. A model whose ratio stays near 1 - the reference's trained i_v3_1
+ * (model/save/i_v3_1_2021-05-28_12-40: states of 4e5 from layer 13 on) repeats EVERY structure - pays split + exact on every call and
+ * belongs on PESTO_PRECISION_FP32; the Python layer logs that once (logging "pesto_amd", WARNING). No reference counterpart. */
+int pesto_get_auto_counters(const pesto_model* m, int64_t* n_structures, int64_t* n_repeated);
 /* enabled != 0: device-pointer forwards under PESTO_PRECISION_AUTO return without synchronising; their range / input check is made by
  * the next call on the handle (see pesto_precision). Default 0: checked before the call returns. No reference counterpart. */
 int pesto_set_async_auto(pesto_model* m, int32_t enabled);

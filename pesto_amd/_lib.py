@@ -63,6 +63,7 @@ ABI_SYMBOLS = [
     "pesto_set_precision", "pesto_get_status", "pesto_debug_select", "pesto_forward_structures",
     "pesto_mask_to_segments", "pesto_debug_edge_mode", "pesto_forward_batch_submit", "pesto_forward_batch_wait",
     "pesto_set_async_auto", "pesto_debug_host_only", "pesto_knn_tie_rows", "pesto_set_auto_state_limit", "pesto_set_auto_pad_trigger",
+    "pesto_get_auto_counters",
 ]
 
 _lib = None
@@ -109,6 +110,7 @@ def load():
     lib.pesto_set_auto_pad_trigger.argtypes = [c_p, i32]
     lib.pesto_debug_host_only.argtypes = [c_p, i32]
     lib.pesto_get_status.argtypes = [c_p, P(i32), P(i64), P(i64)]
+    lib.pesto_get_auto_counters.argtypes = [c_p, P(i64), P(i64)]
     lib.pesto_debug_select.argtypes = [c_p, i32, i32]
     lib.pesto_debug_edge_mode.argtypes = [c_p, i32]
     lib.pesto_mask_to_segments.argtypes = [c_p, i64, i64, c_p, c_p, i32, c_p]

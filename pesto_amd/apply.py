@@ -206,7 +206,8 @@ def _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_erro
             hand_out(done)
 
         group, atoms = [], 0
-        small, small_atoms = [], 0      # structures of fewer than 64 atoms (zero-padded neighbour slots): launches of their own - precision "auto"
+        pad_cols = model.max_nn         # (neighbour slots a layer reads)
+        small, small_atoms = [], 0      # structures of fewer atoms than that (zero-padded neighbour slots): launches of their own - precision "auto"
                                         # repeats them on the exact kernels, and that repeat covers the whole launch (sharding.forward_local)
         for path, fut in loads:
             try:
@@ -215,7 +216,7 @@ def _apply_loop(model, pdb_filepaths, write, suffix, max_atoms, workers, on_erro
                 if on_error:
                     on_error(f"error with {path}: {e}")
                 continue
-            if len(s) < 64:
+            if len(s) < pad_cols:
                 if small and small_atoms + len(s) > max_atoms:
                     flush(small)
                     small, small_atoms = [], 0

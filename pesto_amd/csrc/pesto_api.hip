@@ -67,6 +67,7 @@ struct pesto_model {
     bool knn_brute = false;                // pesto_debug_select: brute-force k-NN for every structure
     int edge_mode = 0;                     // pesto_debug_edge_mode: 0 = per launch, 1 = rendezvous, 2 = node waves
     int64_t n_forward = 0, n_rerun = 0;    // launch sequences run / STRUCTURES repeated on the exact fp32 kernels after a range overflow
+    int64_t n_struct_auto = 0;             // structures (frames, collated calls) forwarded on the split kernels under PESTO_PRECISION_AUTO
     DevBuf sflags;                         // range guard: one word per structure (frame) of the launch (SatCtx)
     std::vector<int> h_sflags;             // host copy (counting the structures a repeat covers)
     hipEvent_t ev_flags = nullptr;         // recorded behind the early copy of the flags word (run_forward): AUTO's check does not wait for the pool kernels
@@ -162,6 +163,13 @@ int ensure_workspace(pesto_model* m, int64_t N, int64_t R) {
     return rc ? fail(PESTO_ERR_NOMEM, "device workspace allocation failed for N=%lld R=%lld", (long long)N, (long long)R) : 0;
 }
 
+// the largest neighbourhood a layer of the model gathers from (<= KMAX)
+int max_nn(const pesto_model* m) {
+    int v = 0;
+    for (int l = 0; l < m->cfg.n_layers; ++l) v = std::max(v, m->cfg.nn[l]);
+    return v;
+}
+
 // flags buffer layout: [1] error flag (int); per-frame max(D) bit patterns live in m->dmax
 unsigned* dmax_ptr(pesto_model* m) { return m->dmax.as<unsigned>(); }
 int* err_ptr(pesto_model* m) { return m->flags.as<int>() + 1; }
@@ -252,6 +260,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
     int* seg_hi = seg_lo + RT;
     const bool bounds_in_embed = a.F == 1;             // found by the unpack launch (trajectory batches expand res_of_atom per frame behind it: separate launches)
     m->n_forward += 1;
+    if (!exact && m->precision == PESTO_PRECISION_AUTO) m->n_struct_auto += (int64_t)(a.seg_of_atom ? a.n_seg : a.F);      // (= the launch's guard words)
     const int* roa = a.roa;
     if (a.F > 1) {
         if (m->roa_f.ensure((size_t)NT * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
@@ -268,7 +277,7 @@ int run_forward(pesto_model* m, hipStream_t st, const FwdArgs& a, bool exact, bo
     // dependent launch less per forward: 38 -> 37)
     const bool merge_u2 = !exact && m->impl == 2 && unpack2_merge_blocks((int)NT, N1) > 0;
     launch_unpack(st, (int)a.N, (int)a.F, a.k, a.X, a.xs_frame, a.xs_atom, a.ids, a.ids_kind, m->ids_s.as<int>(), m->geo.as<float4>(),
-                  dmax_ptr(m), err_ptr(m), a.seg_of_atom, a.seg_end, sb, merge_u2);
+                  dmax_ptr(m), err_ptr(m), a.seg_of_atom, a.seg_end, sb, merge_u2, max_nn(m));
     if (a.F > 1) launch_expand_roa(st, (int)a.N, (int)a.R, (int)a.F, a.roa, m->roa_f.as<int>(), err_ptr(m));
     if (m->timing) HIP_TRY(hipEventRecord(m->ev[1], st));
     int cur = 0;
@@ -559,6 +568,14 @@ int pesto_get_status(const pesto_model* m, int32_t* precision, int64_t* n_forwar
     if (precision) *precision = m->precision;
     if (n_forward) *n_forward = m->n_forward;
     if (n_fp32_rerun) *n_fp32_rerun = m->n_rerun;
+    return 0;
+}
+
+int pesto_get_auto_counters(const pesto_model* m, int64_t* n_structures, int64_t* n_repeated) {
+    if (check_model(m)) return PESTO_ERR_INVALID;
+    if (int rc = resolve_pending(const_cast<pesto_model*>(m))) return rc;
+    if (n_structures) *n_structures = m->n_struct_auto;
+    if (n_repeated) *n_repeated = m->n_rerun;
     return 0;
 }
 
@@ -1021,7 +1038,7 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
         host_tab[n_struct + 1 + s] = (!brute && struct_offsets[s + 1] - struct_offsets[s] >= knn_cell_min()) ? n_slots++ : -1;
     const int use_grid = n_slots > 0;
     if (m->knn_off.ensure(host_tab.size() * 4)) return fail(PESTO_ERR_NOMEM, "workspace allocation failed");
-    m->knn_off_host.assign(struct_offsets, struct_offsets + n_struct + 1);      // (what the upload below leaves on the device)
+    m->knn_off_host.clear();      // (the device copy is about to change: valid again only once the upload below has been queued - ADVICE r5)
     if (use_grid) {
         const size_t cells = (size_t)n_slots * knn_cells_per_struct();
         if (m->knn_grids.ensure((size_t)n_struct * knn_grid_struct_bytes()) || m->knn_cnt.ensure(cells * 4) || m->knn_cur.ensure(cells * 4) ||
@@ -1039,6 +1056,7 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
         if (seq.rc) return seq.rc;
         HIP_TRY(hipMemcpyAsync(m->knn_off.p, host_tab.data(), host_tab.size() * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));     // host_tab is a local: finish the copy before returning
+        m->knn_off_host.assign(struct_offsets, struct_offsets + n_struct + 1);      // (what the device holds now)
         knn_launch(st, X, ids_out);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -1054,6 +1072,7 @@ int pesto_knn_collate(pesto_model* m, int64_t n_total, int32_t n_struct, const i
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ids_out, m->in_ids.p, (size_t)n_total * KMAX * id_sz, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    m->knn_off_host.assign(struct_offsets, struct_offsets + n_struct + 1);      // (the upload has completed)
     return 0;
 }
 

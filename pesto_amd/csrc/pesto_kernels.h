@@ -40,7 +40,8 @@ void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq,
 // calls - per-structure wrap-around target and max(D); dmax_bits then holds one zeroed word per structure
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
                    int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag, const int* seg_of_atom = nullptr,
-                   const int* seg_end = nullptr, SegBoundsArgs sb = SegBoundsArgs(), bool skip_pass2 = false);
+                   const int* seg_end = nullptr, SegBoundsArgs sb = SegBoundsArgs(), bool skip_pass2 = false, int pad_cols = KMAX);
+// pad_cols: neighbour columns a layer can gather from (the config's largest nn): zero ids in THEM are padded slots for AUTO's pad trigger
 // pass 2 of the geometry (D += max(D) (D < 1e-2), R /= D, sink row; src/model_operations.py:12-20) as extra workgroups of the node launch
 // that writes the first layer's records: small launches (one structure) then pay one dependent launch less (round 5). n = N atoms in total.
 struct Unpack2Args { int n = 0; int Nf = 0; int* ids_s = nullptr; float4* geo = nullptr; const unsigned* dmax_bits = nullptr; const int* seg_of_atom = nullptr; };

@@ -123,7 +123,9 @@ template <typename IdT>
 __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __restrict__ X, int64_t xs_frame, int64_t xs_atom,
                                                  const IdT* __restrict__ ids, int* __restrict__ ids_s, float4* __restrict__ geo,
                                                  unsigned* __restrict__ dmax_bits, int* __restrict__ err_flag,
-                                                 const int* __restrict__ seg_of_atom, const int* __restrict__ seg_end, SegBoundsArgs sb) {
+                                                 const int* __restrict__ seg_of_atom, const int* __restrict__ seg_end, SegBoundsArgs sb, int pad_cols) {
+    // pad_cols: the columns a layer can gather from (the largest nn of the config): a zero id in one of THEM is a padded slot for the
+    // conditioning trigger; zero padding behind them (a table of k < 64 columns under a model whose layers use at most k) is never read
     // (sb: the residue segments of the pool layer, model_operations.py:199-211, only depend on res_of_atom - the thread of an atom's
     //  first slot finds them here, one launch less at the end of the forward)
     float d = 0.0f;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
         const int sg = seg_of_atom[i];
         long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
         if (id < 0 || id > Nf) { atomicOr(err_flag, 1); id = 0; }
-        if (__ballot(id == 0) != 0 && (threadIdx.x & 63) == 0) pad_flag_at(err_flag, (int64_t)i + 1);      // (a wave = the 64 slots of one atom)
+        if (__ballot(id == 0 && c < pad_cols) != 0 && (threadIdx.x & 63) == 0) pad_flag_at(err_flag, (int64_t)i + 1);      // (a wave = the 64 slots of one atom)
         const long long j = id > 0 ? id - 1 : (long long)seg_end[sg] - 1;
         const float* xj = Xf + j * xs_atom;
         const float* xi = Xf + (int64_t)i * xs_atom;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void k_unpack1(int Nf, int k, const float* __r
         if (sb.roa && c == 0) seg_bound_atom(i, sb.R, sb.roa, sb.lo_enc, sb.hi, sb.err_flag);
         long long id = c < k ? (long long)ids[(size_t)i * k + c] : 0;
         if (id < 0 || id > Nf) { atomicOr(err_flag, 1); id = 0; }
-        padded = padded || id == 0;
+        padded = padded || (id == 0 && c < pad_cols);
         long long j = id - 1;
         if (j < 0) j += Nf;
         const float* xj = Xf + j * xs_atom;
@@ -620,16 +622,16 @@ void launch_embed(hipStream_t st, const float* W, const MlpW& em, int N, int nq,
 
 void launch_unpack(hipStream_t st, int Nf, int F, int k, const float* X, int64_t xs_frame, int64_t xs_atom, const void* ids,
                    int ids_kind, int* ids_s, float4* geo, unsigned* dmax_bits, int* err_flag, const int* seg_of_atom, const int* seg_end,
-                   SegBoundsArgs sb, bool skip_pass2) {
+                   SegBoundsArgs sb, bool skip_pass2, int pad_cols) {
     const int64_t n1 = (int64_t)Nf * KMAX, nall = (int64_t)Nf * F * KMAX;
     const dim3 grid1((unsigned)((n1 + (seg_of_atom ? 255 : 1023)) / (seg_of_atom ? 256 : 1024)), (unsigned)F),
         grid2((unsigned)((nall + KMAX + 255) / 256));
     if (ids_kind == PESTO_IDS_INT64)
         hipLaunchKernelGGL(k_unpack1<long long>, grid1, dim3(256), 0, st, Nf, k, X, xs_frame, xs_atom, (const long long*)ids, ids_s, geo,
-                           dmax_bits, err_flag, seg_of_atom, seg_end, sb);
+                           dmax_bits, err_flag, seg_of_atom, seg_end, sb, pad_cols);
     else
         hipLaunchKernelGGL(k_unpack1<int>, grid1, dim3(256), 0, st, Nf, k, X, xs_frame, xs_atom, (const int*)ids, ids_s, geo, dmax_bits,
-                           err_flag, seg_of_atom, seg_end, sb);
+                           err_flag, seg_of_atom, seg_end, sb, pad_cols);
     if (!skip_pass2) hipLaunchKernelGGL(k_unpack2, grid2, dim3(256), 0, st, Nf * F, Nf, ids_s, geo, dmax_bits, seg_of_atom);      // (else: inside the node launch, launch_node)
 }
 

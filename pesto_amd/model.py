@@ -45,6 +45,7 @@ class Model:
         self._cc = _lib.make_c_config(self.config, self.precision)
         self._debug = (0, 0)        # pesto_debug_select(layer_kernels, knn_brute_force): test hook
         self._edge_mode = 0         # pesto_debug_edge_mode: test hook
+        self._auto_bill_logged = False
         self._state_limit = None    # pesto_set_auto_state_limit (None: library default)
         self._pad_trigger = None    # pesto_set_auto_pad_trigger (None: library default = on)
         self._last_device_call = None           # async_auto: tensors of the last device call (kept alive for its deferred check)
@@ -126,6 +127,36 @@ class Model:
         _lib.check(_lib.load().pesto_get_status(self._ensure(), ctypes.byref(p), ctypes.byref(a), ctypes.byref(b)))
         return {"precision": {v: k for k, v in _lib.PRECISIONS.items()}[p.value], "n_forward": a.value, "n_fp32_rerun": b.value}
 
+    def auto_counters(self):
+        """{"n_structures", "n_repeated"}: structures forwarded on the split kernels under precision "auto" and how many of them were
+        computed again on the exact fp32 kernels (pesto_get_auto_counters)."""
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.load().pesto_get_auto_counters(self._ensure(), ctypes.byref(a), ctypes.byref(b)))
+        return {"n_structures": a.value, "n_repeated": b.value}
+
+    def _tick_auto_bill(self, every=16):
+        """called behind a forward: looks at the counters every ``every``-th call until the warning has been given"""
+        if self._auto_bill_logged:
+            return
+        self._auto_calls = getattr(self, "_auto_calls", 0) + 1
+        if self._auto_calls % every == 0:
+            self._note_auto_bill()
+
+    def _note_auto_bill(self):
+        """Once per model: a WARNING (logging "pesto_amd") when "auto" has repeated at least 90 % of >= 16 structures - such a model (the
+        reference's trained i_v3_1) pays the split AND the exact kernels on every structure and is ~1.4x faster under precision="fp32".
+        Never called where it would synchronise an asynchronous launch (async_auto)."""
+        if self._auto_bill_logged or self.precision != "auto" or self.async_auto or self._handle is None:
+            return
+        c = self.auto_counters()
+        if c["n_structures"] >= 16 and c["n_repeated"] >= 0.9 * c["n_structures"]:
+            import logging
+            logging.getLogger("pesto_amd").warning(
+                "precision='auto' has repeated %d of %d structures on the exact fp32 kernels (an activation left the f16 range, or a "
+                "neighbour table is zero-padded): this model pays the split AND the exact kernels on every call - construct it with "
+                "precision='fp32' (Model(config, precision='fp32') / set_precision('fp32'))", c["n_repeated"], c["n_structures"])
+            self._auto_bill_logged = True
+
     def debug_select(self, layer_kernels=0, knn_brute_force=False):
         """Test hook (pesto_debug_select): 0 = shipped kernels, 1 = fp32 VALU reference-formulation kernel; brute-force k-NN."""
         self._debug = (int(layer_kernels), int(bool(knn_brute_force)))
@@ -137,6 +168,12 @@ class Model:
         """Measurement hook (pesto_debug_host_only): forward_batch_submit does its host half only; the wait returns zeros."""
         _lib.check(_lib.load().pesto_debug_host_only(self._ensure(), 1 if enabled else 0))
         return self
+
+    @property
+    def max_nn(self):
+        """The largest neighbourhood a layer gathers from: a structure with fewer atoms (or a neighbour table with fewer columns) has
+        zero-padded slots a layer reads - what precision "auto" repeats on the exact kernels (pesto_set_auto_pad_trigger)."""
+        return max(int(l["nn"]) for l in self.config["sum"])
 
     def debug_edge_mode(self, mode=0):
         """Test hook (pesto_debug_edge_mode): 0 = work decomposition of the state-update kernel chosen per launch, 1 = rendezvous
@@ -297,6 +334,7 @@ class Model:
             # (or synchronize()), which may repeat flagged structures on the fp32 kernels into the same z - the launch's buffers stay
             # referenced until then.
             self._last_device_call = (Xc, ids, qc, roa, z) if self.async_auto else None
+            self._tick_auto_bill()
             return z
         # host path: CPU torch tensors or numpy arrays
         as_torch = _is_torch(X)
@@ -313,6 +351,7 @@ class Model:
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         _lib.check(call(N, k, p(Xn), p(idn), _lib.IDS_INT64 if idn.dtype == np.int64 else _lib.IDS_INT32,
                         p(qn), p(roa), p(z), _lib.PTR_HOST, None))
+        self._tick_auto_bill()
         if as_torch:
             import torch
             return torch.from_numpy(z)
@@ -379,6 +418,7 @@ class Model:
             Xp[b], Ip[b], Qp[b], Ap[b], Zp[b] = Xn.ctypes.data, idn.ctypes.data, qn.ctypes.data, roa.ctypes.data, z.ctypes.data
         _lib.check(lib.pesto_forward_batch(h, nb, Np, Rp, kp, Xp, Ip, _lib.IDS_INT64 if kind == np.int64 else _lib.IDS_INT32, Qp, Ap, Zp,
                                            _lib.BATCH_INDEPENDENT if independent else _lib.BATCH_COLLATED, None))
+        self._tick_auto_bill(every=1)
         return zs
 
     # ------------------------------------------------------------------ pipelined launches (SURVEY 8b threading row)
@@ -482,6 +522,7 @@ class Model:
         if zs is None:
             raise ValueError(f"no launch in flight under ticket {ticket}")
         _lib.check(_lib.load().pesto_forward_batch_wait(self._ensure(), ticket))
+        self._tick_auto_bill(every=1)
         return zs
 
     # ------------------------------------------------------------------ trajectory frames

@@ -109,13 +109,15 @@ def forward_local(forward_fn, structures, indices, max_atoms=24576, raise_if_all
             r0 += r
 
     last_error = None
-    # structures with zero-padded neighbour slots (fewer than 64 atoms / columns) get launches of their own: precision "auto" repeats such
+    # structures with zero-padded neighbour slots a layer reads (fewer atoms / table columns than the model's largest nn) get launches of their own: precision "auto" repeats such
     # structures on the exact fp32 kernels (pesto_set_auto_pad_trigger), and the repeat runs the exact kernels over the WHOLE launch of a
     # flagged structure (writing only its logits) - one peptide must not make 24,000 atoms of batch mates pay for it. Results do not
     # depend on the grouping (PESTO_BATCH_INDEPENDENT), so this is a cost decision only.
+    pad_cols = int(getattr(forward_fn, "max_nn", 64))      # (a plain callable: the full table width)
+
     def _padded(i):
         ids = structures[i][1]
-        return sizes[i] < 64 or (np.ndim(ids) == 2 and np.shape(ids)[1] < 64)
+        return sizes[i] < pad_cols or (np.ndim(ids) == 2 and np.shape(ids)[1] < pad_cols)
     small = [i for i in indices if _padded(i)]
     groups = batches([i for i in indices if not _padded(i)], sizes, max_atoms) + (batches(small, sizes, max_atoms) if small else [])
     # a pesto_amd.Model: two launches in flight (submit t + 1 while t computes: host packing and the H2D copy overlap the kernels)
@@ -303,10 +305,88 @@ def broadcast_weights(model, state_dict=None, src=0, device=None):
     return {"bytes": int(n) * 4, "sha256_16": h, "ranks_equal": True, "backend": backend}
 
 
-def describe_ranks(device=None):
+def _parse_cpulist(s):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)"""
+    out = []
+    for part in s.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def numa_node_of_pci(pci_bus_id, sysfs="/sys"):
+    """NUMA node of a PCI device ('0000:0a:00' or '0000:0a:00.0'), or None where sysfs does not say (-1: a single-node host, a container
+    without /sys/bus/pci)."""
+    import os
+    bdf = pci_bus_id if "." in pci_bus_id else pci_bus_id + ".0"
+    try:
+        node = int(open(os.path.join(sysfs, "bus", "pci", "devices", bdf.lower(), "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return None
+    return node if node >= 0 else None
+
+
+def bind_rank_to_numa(device=None, sysfs="/sys", set_omp=True, max_threads=None):
+    """Pin this process - one rank per GPU - to the CPUs of its GPU's NUMA node (the reference feeds its loop from
+    DataLoader(num_workers=8), interfaceome/apply_model.py:49-50; here the rank's own threads pack and copy launches from host memory,
+    0.85 ms of host CPU per structure: on a two-socket host a rank on the far socket pays the inter-socket link for every byte it packs
+    and uploads). Reads /sys/bus/pci/devices/<bdf>/numa_node for the PCI bus id of the rank's device and /sys/devices/system/node/
+    node<N>/cpulist, intersects with the CPUs the process may already use (a container's cpuset), calls os.sched_setaffinity and sets
+    OMP_NUM_THREADS for libraries loaded afterwards. Returns {"numa_node", "cpus_allowed", "cpu_list_head", "bound", "why"}; binds nothing
+    (bound False, with the reason) where the node is unknown - never an error: the placement is an optimisation."""
+    import os
+    info = {"numa_node": None, "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cpu_list_head": None, "bound": False, "why": None}
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            info["why"] = "no GPU"
+            return info
+        d = torch.cuda.current_device() if device is None else torch.device(device).index
+        pr = torch.cuda.get_device_properties(d)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+    except Exception as e:      # noqa: BLE001 - describing a device must not take the run down
+        info["why"] = f"device properties unavailable: {e}"
+        return info
+    return _bind_to_node_of(bdf, info, sysfs, set_omp, max_threads)
+
+
+def _bind_to_node_of(bdf, info, sysfs="/sys", set_omp=True, max_threads=None):
+    import os
+    node = numa_node_of_pci(bdf, sysfs)
+    info["numa_node"] = node
+    if node is None:
+        info["why"] = f"{sysfs}/bus/pci/devices/{bdf}.0/numa_node gives no node (single-node host or no sysfs)"
+        return info
+    try:
+        cpus = set(_parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read()))
+    except OSError as e:
+        info["why"] = f"no cpulist of node {node}: {e}"
+        return info
+    if hasattr(os, "sched_getaffinity"):
+        cpus &= set(os.sched_getaffinity(0))      # (a container's cpuset: never ask for a CPU the process may not use)
+    if not cpus:
+        info["why"] = f"node {node} has no CPU this process may use"
+        return info
+    try:
+        os.sched_setaffinity(0, cpus)
+    except (OSError, AttributeError) as e:
+        info["why"] = f"sched_setaffinity failed: {e}"
+        return info
+    n_thr = len(cpus) if max_threads is None else min(len(cpus), int(max_threads))
+    if set_omp:
+        os.environ["OMP_NUM_THREADS"] = str(n_thr)
+    info.update({"cpus_allowed": len(cpus), "cpu_list_head": sorted(cpus)[:4], "bound": True, "omp_num_threads": n_thr})
+    return info
+
+
+def describe_ranks(device=None, numa=None):
     """What the collective library actually sees - for a bench line that must explain itself on hardware nobody could test on:
     ranks_seen = an all_reduce(SUM) of ones (device tensors under nccl: RCCL carried it), and per rank the device it computes on
-    (name, PCI bus id, device ordinal, host). {"world", "ranks_seen", "backend", "devices": [...]}; without a process group: world 1."""
+    (name, PCI bus id, device ordinal, host; with ``numa`` = the dict bind_rank_to_numa returned: its NUMA node and the CPUs it is pinned
+    to). {"world", "ranks_seen", "backend", "devices": [...]}; without a process group: world 1."""
     import socket
     import torch
     import torch.distributed as dist
@@ -316,6 +396,9 @@ def describe_ranks(device=None):
         pr = torch.cuda.get_device_properties(d)
         me.update({"device": int(d), "device_name": pr.name, "pci_bus_id": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}",
                    "gcn_arch": getattr(pr, "gcnArchName", None), "hbm_GiB": round(pr.total_memory / 2 ** 30, 1)})
+    if numa is not None:
+        me.update({"numa_node": numa.get("numa_node"), "cpus_allowed": numa.get("cpus_allowed"), "cpu_list_head": numa.get("cpu_list_head"),
+                   "numa_bound": numa.get("bound"), "numa_why": numa.get("why")})
     if not (dist.is_available() and dist.is_initialized()):
         return {"world": 1, "ranks_seen": 1, "backend": None, "devices": [me]}
     backend = dist.get_backend()

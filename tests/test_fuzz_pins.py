@@ -190,3 +190,35 @@ def test_auto_pad_trigger_repeats_exactly_the_padded_structures():
     assert np.array_equal(zc, _model("fp32").forward_segments(L["X"], L["ids"], L["q0"], L["roa"], L["R"]))
     mf = _model("f16_split", pad_trigger=True)
     assert all(np.array_equal(a, b) for a, b in zip(mf.forward_batch(structs, independent=True), split))
+
+
+@pytest.mark.gpu
+def test_pad_trigger_looks_at_the_columns_a_layer_reads():
+    """the trigger compares against the model's LARGEST nn, not the table width of 64 - a k = 32 neighbour table under a model
+    whose layers gather at most 16 neighbours has no padded slot any layer reads (no repeat, the split kernels' bits), the same structure
+    with an 8-column table has (repeated on the exact kernels: equal to precision "fp32" bit for bit). Same bound in Model.max_nn, which
+    the bulk loops' grouping (sharding.forward_local, apply) uses."""
+    import copy
+    from pesto_amd import Model
+    from pesto_amd.topology import extract_topology, mask_to_segments, synthetic_structure
+    from pesto_amd.weights import synthetic_state_dict
+    cfg = copy.deepcopy(CONFIGS["i_v4_0"])
+    cfg["sum"] = [dict(cfg["sum"][0], nn=8), dict(cfg["sum"][0], nn=16)]
+    sd = synthetic_state_dict(cfg, seed=3)
+    X, ids0, q, M = synthetic_structure(200, 9)
+    roa, R = mask_to_segments(M)
+    ids = (ids0 + 1).astype(np.int32)
+
+    def model(precision):
+        m = Model(cfg, precision=precision)
+        m.load_state_dict(sd)
+        return m.eval()
+
+    assert model("auto").max_nn == 16
+    for k, repeats in ((32, 0), (16, 0), (8, 1)):
+        tab = np.ascontiguousarray(ids[:, :k])
+        m = model("auto")
+        z = m.forward_segments(X, tab, q, roa, R)
+        assert m.status()["n_fp32_rerun"] == repeats, k
+        ref = model("fp32" if repeats else "f16_split").forward_segments(X, tab, q, roa, R)
+        assert np.array_equal(z, ref), k

@@ -825,6 +825,36 @@ def test_softmax_range_is_guarded_not_assumed():
     assert e.value.code == ERR_RANGE
 
 
+def test_auto_says_once_when_it_repeats_every_structure(caplog):
+    """under the default policy the trained i_v3_1 pays the split AND the exact kernels on every structure (its states
+    leave the f16 range). pesto_get_auto_counters counts structures forwarded / repeated; the Python layer logs ONE warning pointing at
+    precision="fp32" once at least 90 % of >= 16 structures were repeated - and nothing for a model that never repeats."""
+    import logging
+    from pesto_amd import Model
+    g = golden("fwd_i_v3_0_2CUA")
+    roa = g["res_of_atom"]
+    args = (g["X"], g["ids_topk"].astype(np.int64), onehot(g["q_idx"], 123), roa, int(roa.max()) + 1)
+    m = Model(CONFIGS["i_v3_1"])
+    m.load_state_dict(weights("i_v3_1_trained"))
+    with caplog.at_level(logging.WARNING, logger="pesto_amd"):
+        for _ in range(15):
+            m.forward_segments(*args)
+        assert m.auto_counters() == {"n_structures": 15, "n_repeated": 15} and not caplog.records
+        for _ in range(20):
+            m.forward_segments(*args)
+        hits = [r for r in caplog.records if "precision='fp32'" in r.getMessage()]
+        assert len(hits) == 1 and "repeated 16 of 16" in hits[0].getMessage()
+    ok = _model("i_v3_0", "mfma")
+    with caplog.at_level(logging.WARNING, logger="pesto_amd"):
+        caplog.clear()
+        for _ in range(33):
+            ok.forward_segments(*args)
+        assert ok.auto_counters() == {"n_structures": 33, "n_repeated": 0} and not caplog.records
+    m.set_precision("fp32")
+    m.forward_segments(*args)
+    assert m.auto_counters()["n_structures"] == 35      # (fp32 forwards are not "auto" structures)
+
+
 def test_trained_i_v3_1_range_guard():
     """The reference's TRAINED i_v3_1 drives its states to 4e5, beyond the f16 range of the split-MFMA kernels. "auto" must notice
     and compute the structure again on the exact fp32 kernels (finite, within the reference's own fp32-vs-fp64 noise) - before the
