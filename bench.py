@@ -17,7 +17,7 @@ Extra objects in the same line:
                   of the instructions the launch issues, at the `clock_GHz` the kernel held); the profile-derived keys come from the
                   committed, hash-stamped PMC passes of this build (null when stale);
   cpu_baseline    the C oracle (a port of the reference CPU path) on this host's cores, bounded sample, plus the
-                  reference-equivalent time rho x t_port (rho measured in the build container, profiles/r02_cpu_rho.json);
+                  reference-equivalent time rho x t_port (rho measured in the build container, profiles/r06_cpu_rho.json);
   config4_sharded BASELINE config 4 as a strong-scaling leg: a FIXED list of 64 structures with the pdbs_test size histogram
                   through pesto_amd.sharding.forward_sharded (nccl, device tensors in the gather), gathered z checked bitwise
                   against a world-1 run (--mode strong makes this leg the headline value);
@@ -149,6 +149,26 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def cpu_quota_cores():
+    """CPUs the cgroup lets this process USE at once (cpu.max quota / period; cgroup v1: cfs_quota_us / cfs_period_us), or None when
+    unlimited / unknown. A box that shows 256 CPUs under a quota of 32 runs 256 OpenMP threads on 32 cores' worth of time."""
+    for q_path, p_path in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if p_path is None:
+                q_, p_ = open(q_path).read().split()[:2]
+            else:
+                q_, p_ = open(q_path).read().strip(), open(p_path).read().strip()
+            if q_ != "max" and float(q_) > 0:
+                return float(q_) / float(p_)
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def oracle_source_sha16():
+    return hashlib.sha256(open(os.path.join(ROOT, "oracle", "pesto_oracle.c"), "rb").read()).hexdigest()[:16]
+
+
 def cpu_baseline(config, sd, n_atoms, budget_s, config_key):
     """The C oracle (port of the reference CPU path, OpenMP over atoms) on this host's cores, bounded sample: once on ALL cores
     (the headline `value`) and once on the thread count rho was measured at (8), so that the reference-equivalent time
@@ -174,24 +194,38 @@ def cpu_baseline(config, sd, n_atoms, budget_s, config_key):
             times.append(time.perf_counter() - t0)
         return float(np.median(times)), len(times), t_warm
 
-    # the port does not scale to every host's core count (shared / hyper-threaded vCPUs): the headline is its BEST team size
+    # the port is timed at doubling team sizes up to the CPUs the process may use; the headline is its BEST team size. Where the curve
+    # stops falling is stated with its reason: the cgroup's CPU quota (a box can show 256 CPUs and grant 32 cores' worth of time) or,
+    # without a quota, the port itself (3,001 equal atoms per layer, one OpenMP loop: memory-bound gathers beyond ~32 threads)
+    quota = cpu_quota_cores()
+    sizes_ = sorted({v for v in (8, 16, 32, 64, 128, 256) if v < all_threads} | {all_threads})
     tried = {}
-    for thr_ in sorted({min(32, all_threads), min(64, all_threads), all_threads}):
-        tried[thr_] = sample(thr_, 0.4 * budget_s / 3, 3)
+    for thr_ in sizes_:
+        tried[thr_] = sample(thr_, 0.4 * budget_s / len(sizes_), 3)
+        if tried[thr_][0] > 3.0 * min(v_[0] for v_ in tried.values()):      # far beyond the knee: larger teams only cost sample time
+            break
     best = min(tried, key=lambda k_: tried[k_][0])
     t, n, t_warm = tried[best]
+    why = (f"cgroup CPU quota = {quota:.0f} cores' worth of time on a host that shows {cores} CPUs" if quota and quota < 0.9 * cores else
+           f"no CPU quota: the port itself stops scaling there (one OpenMP loop over {n_atoms + 1} atoms per layer, gather-bound)")
     out = {"value": 1.0 / t, "unit": "structures/s", "cores": best, "kind": "port",
-           "sample": f"{n} x one N={n_atoms} structure, all {len(config['sum'])} layers, C oracle (OpenMP, {best} threads = the best of "
-                     f"{sorted(tried)} on this host's {cores} cores); median {t:.2f} s/structure (2-layer warm-up {t_warm:.2f} s)",
+           "sample": f"{n} x one N={n_atoms} structure, all {len(config['sum'])} layers, C oracle (OpenMP, passive waits, {best} threads = the best of "
+                     f"{sorted(tried)} on this host's {cores} CPUs; {why}); median {t:.2f} s/structure (2-layer warm-up {t_warm:.2f} s)",
+           "cores_why": why, "cpu_quota_cores": quota, "host_cpus": cores,
            "seconds_per_structure_by_threads": {str(k_): v_[0] for k_, v_ in sorted(tried.items())}}
     # reference-equivalent CPU time = rho x t_port, rho = t_reference / t_port measured on equal cores in the
-    # build container (profiles/cpu_rho.py -> profiles/r02_cpu_rho.json, copied to BASELINE.md) and applied to the port's time at
+    # build container (profiles/cpu_rho.py -> profiles/r06_cpu_rho.json, copied to BASELINE.md) and applied to the port's time at
     # THAT thread count on this host
-    rpath = os.path.join(ROOT, "profiles", "r02_cpu_rho.json")
+    rpath = os.path.join(ROOT, "profiles", "r06_cpu_rho.json")
     if os.path.exists(rpath):
         r = json.load(open(rpath))
         hit = [v for k, v in r["configs"].items() if k.startswith(config_key)]
-        if hit:
+        if r.get("oracle_source_sha16") != oracle_source_sha16():
+            # rho = reference / port on equal cores is a property of THIS port: a ratio measured with another oracle source is refused
+            out["reference_equivalent"] = None
+            out["reference_equivalent_note"] = (f"profiles/r06_cpu_rho.json was measured with oracle source {r.get('oracle_source_sha16')}, the oracle "
+                                                f"timed here is {oracle_source_sha16()}: re-run profiles/cpu_rho.py in the build container")
+        elif hit:
             rho = float(np.mean([v["rho"] for v in hit]))
             thr = int(r["threads"])
             t8, n8, _ = sample(min(thr, all_threads), 0.4 * budget_s, 3)
@@ -202,7 +236,7 @@ def cpu_baseline(config, sd, n_atoms, budget_s, config_key):
                                            "structures_per_s": 1.0 / (rho * t8),
                                            "estimate": True, "rho_machine": "build container (no GPU), not this host",
                                            "provenance": f"rho = reference PyTorch CPU time / C-oracle time on the same {thr} threads of the "
-                                                         f"build container (torch {r['torch']}), profiles/r02_cpu_rho.json, times the port's "
+                                                         f"build container (torch {r['torch']}), profiles/r06_cpu_rho.json (oracle source {r['oracle_source_sha16']}), times the port's "
                                                          f"time at {min(thr, all_threads)} threads on THIS host; the reference itself cannot "
                                                          "run on the GPU box"}
     return out
@@ -413,6 +447,11 @@ def main():
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="atom numbering of the synthetic clouds: generation order, or along a Z-order curve")
     args = ap.parse_args()
+    # the CPU-baseline leg times an OpenMP port at team sizes up to the host's CPU count: under a cgroup CPU quota (or shared vCPUs) an
+    # ACTIVE-waiting team of 256 spins its own time slices away (8 s per structure against 0.6 s at 32 threads in round 5). Passive waits,
+    # set before any OpenMP runtime is loaded, make the curve flat instead of catastrophic beyond the knee.
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("GOMP_SPINCOUNT", "2000")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -850,9 +889,9 @@ def run(args, stage):
             key = {"i_v4_1": "2:", "i_v3_0": "3:"}.get(args.config, "2:")
             out["cpu_baseline"] = cpu_baseline(config, sd, args.atoms, args.cpu_budget, key)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-            if "reference_equivalent" in out["cpu_baseline"]:
+            if out["cpu_baseline"].get("reference_equivalent"):
                 # an ESTIMATE: rho (reference / port) was measured on another machine - the build container, 8 threads
-                # (profiles/r02_cpu_rho.json) - and multiplies the port's time at 8 threads on this host
+                # (profiles/r06_cpu_rho.json) - and multiplies the port's time at 8 threads on this host
                 out["speedup_vs_reference_equivalent_cpu_estimate"] = out["value"] / out["cpu_baseline"]["reference_equivalent"]["structures_per_s"]
         print(json.dumps(out), flush=True)
     if dist is not None:

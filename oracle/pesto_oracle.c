@@ -253,6 +253,8 @@ int oracle_unpack(int64_t N, int k, const float* X, const int32_t* ids, int32_t*
 /* ------------------------------------------------------------------ stage: one state-update layer
  * src/model_operations.py:225-242 (StateUpdateLayer.forward) calling :87-154 (StateUpdate.forward).
  * q [N1,32], p [N1,3,32] (N1 = N+1, row 0 = sink) are updated in place; every row reads the OLD state. */
+static _Thread_local float* tl_scratch = NULL;      /* per-thread edge scratch of oracle_layer (kept for the thread's lifetime) */
+
 int oracle_layer(const struct oracle_model* m, int layer, int64_t N1, int k, const int32_t* ids_s, const float* D,
                  const float* R, float* q, float* p) {
     if (layer < 0 || layer >= m->cfg.n_layers) return -1;
@@ -263,23 +265,28 @@ int oracle_layer(const struct oracle_model* m, int layer, int64_t N1, int k, con
     float* q_old = (float*)malloc(sizeof(float) * (size_t)N1 * S);
     float* p_old = (float*)malloc(sizeof(float) * (size_t)N1 * 3 * S);
     float* pn = (float*)malloc(sizeof(float) * (size_t)N1 * S);        /* ||p|| over xyz, per atom */
-    memcpy(q_old, q, sizeof(float) * (size_t)N1 * S);
-    memcpy(p_old, p, sizeof(float) * (size_t)N1 * 3 * S);
-    for (int64_t i = 0; i < N1; ++i)
-        for (int s = 0; s < S; ++s) {
-            const float* pi = p_old + i * 3 * S;
-            pn[i * S + s] = sqrtf(pi[s] * pi[s] + pi[S + s] * pi[S + s] + pi[2 * S + s] * pi[2 * S + s]);   /* :105, :113 */
-        }
     mlp_tr t_eq = transpose_mlp(&L->eqkm), t_ep = transpose_mlp(&L->epkm), t_ev = transpose_mlp(&L->evm);
 
 #pragma omp parallel
     {
-        float* Xe = (float*)malloc(sizeof(float) * 64 * XE);
-        float* H0 = (float*)malloc(sizeof(float) * 64 * 64);
-        float* H1 = (float*)malloc(sizeof(float) * 64 * 64);
-        float* Kq = (float*)malloc(sizeof(float) * 64 * NK);
-        float* Kp = (float*)malloc(sizeof(float) * 64 * 3 * NK);
-        float* V = (float*)malloc(sizeof(float) * 64 * 2 * S);
+        /* per-thread scratch, allocated ONCE per thread (the first layer a thread works on) and kept: 32 layers x 256 threads x six
+         * malloc / free pairs inside the parallel region serialised on the allocator */
+        if (!tl_scratch) tl_scratch = (float*)malloc(sizeof(float) * (64 * XE + 2 * 64 * 64 + 64 * NK + 64 * 3 * NK + 64 * 2 * S));
+        float* Xe = tl_scratch;
+        float* H0 = Xe + 64 * XE;
+        float* H1 = H0 + 64 * 64;
+        float* Kq = H1 + 64 * 64;
+        float* Kp = Kq + 64 * NK;
+        float* V = Kp + 64 * 3 * NK;
+        /* the old state and ||p||: copied / computed by the team (was a serial prologue per layer) */
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < N1; ++i) {
+            memcpy(q_old + i * S, q + i * S, sizeof(float) * S);
+            memcpy(p_old + i * 3 * S, p + i * 3 * S, sizeof(float) * 3 * S);
+            const float* pi = p + i * 3 * S;
+            for (int s = 0; s < S; ++s)
+                pn[i * S + s] = sqrtf(pi[s] * pi[s] + pi[S + s] * pi[S + s] + pi[2 * S + s] * pi[2 * S + s]);   /* :105, :113 */
+        }
 #pragma omp for schedule(static, 2)   /* equal-cost atoms: no shared work counter (dynamic chunks of 16 left 68 of 256 threads idle) */
         for (int64_t i = 0; i < N1; ++i) {
             const float* qi = q_old + i * S;
@@ -346,7 +353,6 @@ int oracle_layer(const struct oracle_model* m, int layer, int64_t N1, int k, con
                 for (int s = 0; s < S; ++s) p[i * 3 * S + x * S + s] = pi[x * S + s] + ph[s];   /* :152 */
             }
         }
-        free(Xe); free(H0); free(H1); free(Kq); free(Kp); free(V);
     }
     for (int s = 0; s < S; ++s) q[s] = q[s] * 0.0f;                    /* :239 sink */
     for (int s = 0; s < 3 * S; ++s) p[s] = p[s] * 0.0f;                /* :240 */

@@ -1036,27 +1036,30 @@ __global__ __launch_bounds__(256) void k_postprocess(int N, int R, int n_out, co
 // 2,048 workgroups instead of one per four rows: no tail of tiny workgroups). Every valid row marks its column in `seen` with the
 // call's generation number (no clearing launch); k_mask_check poisons roa[0] when a column stayed empty. No host round trip: a
 // poisoned entry fails the residue-column check of the forward that consumes the array.
-__device__ __forceinline__ void mask_scan4(const float4 v, int c4, int& cnt, int& col) {
-    if (v.x > 0.5f) { ++cnt; col = 4 * c4; }
-    if (v.y > 0.5f) { ++cnt; col = 4 * c4 + 1; }
-    if (v.z > 0.5f) { ++cnt; col = 4 * c4 + 2; }
-    if (v.w > 0.5f) { ++cnt; col = 4 * c4 + 3; }
+typedef float mask_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mask_scan4(const mask_f4 v, int c4, int& cnt, int& col) {
+    if (v[0] > 0.5f) { ++cnt; col = 4 * c4; }
+    if (v[1] > 0.5f) { ++cnt; col = 4 * c4 + 1; }
+    if (v[2] > 0.5f) { ++cnt; col = 4 * c4 + 2; }
+    if (v[3] > 0.5f) { ++cnt; col = 4 * c4 + 3; }
 }
 __global__ __launch_bounds__(256) void k_mask_to_segments(int N, int R, const float* __restrict__ M, int* __restrict__ roa, int* __restrict__ seen, int gen) {
     const int lane = threadIdx.x & 63;
     const int R4 = R >> 2;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const mask_f4 zero4 = mask_f4{0.f, 0.f, 0.f, 0.f};
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < N; i += gridDim.x * 4) {
         const float* row = M + (size_t)i * R;
         int cnt = 0, col = -1;
         int c0 = 0;
         if ((((size_t)row) & 15) == 0) {
-            const float4* row4 = reinterpret_cast<const float4*>(row);
+            const mask_f4* row4 = reinterpret_cast<const mask_f4*>(row);
             for (int c = lane; c < R4; c += 256) {
-                const float4 v0 = row4[c];
-                const float4 v1 = c + 64 < R4 ? row4[c + 64] : zero4;
-                const float4 v2 = c + 128 < R4 ? row4[c + 128] : zero4;
-                const float4 v3 = c + 192 < R4 ? row4[c + 192] : zero4;
+                // (streaming loads: the mask is read once and is larger than the Infinity Cache - it must not evict the weights, records and
+                // states the layer kernels behind it work on)
+                const mask_f4 v0 = __builtin_nontemporal_load(row4 + c);
+                const mask_f4 v1 = c + 64 < R4 ? __builtin_nontemporal_load(row4 + c + 64) : zero4;
+                const mask_f4 v2 = c + 128 < R4 ? __builtin_nontemporal_load(row4 + c + 128) : zero4;
+                const mask_f4 v3 = c + 192 < R4 ? __builtin_nontemporal_load(row4 + c + 192) : zero4;
                 mask_scan4(v0, c, cnt, col); mask_scan4(v1, c + 64, cnt, col); mask_scan4(v2, c + 128, cnt, col); mask_scan4(v3, c + 192, cnt, col);
             }
             c0 = R4 << 2;

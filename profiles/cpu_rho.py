@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import make_golden as mg   # noqa: E402  (reference import helpers)
 
 
+OUT_NAME = "r06_cpu_rho.json"      # (rounds 2 - 5: r02_cpu_rho.json, measured with the round-2 oracle)
+
+
 def median_time(fn, runs):
     fn()
     ts = []
@@ -36,13 +39,18 @@ def median_time(fn, runs):
 
 def main():
     quick = "--quick" in sys.argv
+    core = "--core" in sys.argv      # configs 1 - 3 only (the ones bench.py's reference_equivalent uses), three runs each, on a QUIET machine
     from conftest import weights
     from oracle import oracle
     from pesto_amd.config import CONFIGS
     from pesto_amd.topology import mask_to_segments
     threads = pt.get_num_threads()
     os.environ["OMP_NUM_THREADS"] = str(threads)
-    out = {"threads": threads, "torch": pt.__version__, "configs": {}}
+    import hashlib
+    osrc = os.path.join(ROOT, "oracle", "pesto_oracle.c")
+    out = {"threads": threads, "torch": pt.__version__, "oracle_source_sha16": hashlib.sha256(open(osrc, "rb").read()).hexdigest()[:16],
+           "note": "rho is a property of (reference, port) on equal cores: bench.py refuses a file whose oracle_source_sha16 is not the hash of the "
+                   "oracle source it times (VERDICT r5 item 8)", "configs": {}}
 
     cfg40, m40 = mg.load_run("i_v4_0_2021-09-07_11-20")
     cfg41, Model41, _ = mg.import_reference("i_v4_1_2021-09-07_11-21")
@@ -62,13 +70,15 @@ def main():
         out["configs"][name] = {"atoms": int(X.shape[0]), "t_reference_s": t_ref, "t_port_s": t_port, "rho": t_ref / t_port,
                                 "runs_reference_s": all_ref, "runs_port_s": all_port}
         print(f"{name}: N={X.shape[0]} reference {t_ref:.2f} s, port {t_port:.2f} s, rho {t_ref / t_port:.1f}", flush=True)
-        json.dump(out, open(os.path.join(ROOT, "profiles", "r02_cpu_rho.json"), "w"), indent=1)
+        json.dump(out, open(os.path.join(ROOT, "profiles", OUT_NAME), "w"), indent=1)
 
     runs = 3
     st = mg.parse_pdb(os.path.join(mg.REF, "pdbs_test", "AY_2AYO_1_A:0.pdb"))
     case("1: i_v4_1 (stacked weights), pdbs_test 2AYO chain", m41, "i_v4_1", mg.encode(st, False), runs)
     case("2: i_v4_1, synthetic N=3000", m41, "i_v4_1", mg.synth_inputs(3000, 1), runs)
     case("3: i_v3_0, synthetic N=3000", m30, "i_v3_0", mg.synth_inputs(3000, 1, n0=123), runs)
+    if core:
+        return
     # config 4: the reference runs one chain per call; three chains spanning the size range stand for the 53
     for name in ("V9_2V9T_1_B:0", "WU_2WUS_1_A:0", "NV_3NVN_1_A:0"):
         st = mg.parse_pdb(os.path.join(mg.REF, "pdbs_test", name + ".pdb"))
