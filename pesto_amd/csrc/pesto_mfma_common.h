@@ -234,17 +234,23 @@ __device__ __forceinline__ void mfma16_multi(const float* __restrict__ wf, int m
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xfffffffc, 0x00020000);
 }
+// AUX = cache-policy bits of the instruction (gfx950: 1 = sc0, 2 = nt, 16 = sc1), 0 = default. Measured for the data a launch reads ONCE
+// (centre records, edge rows; profiles/r06_streaming_loads_ab.txt): nt loads are 6.5 % SLOWER on the step, sc1 loads change nothing -
+// every load of the layer kernels uses the default policy. (nt pays on the 288 MB dense mask, which is larger than the Infinity Cache.)
+template <int AUX = 0>
 __device__ __forceinline__ f32x4 bufld4(__amdgpu_buffer_rsrc_t r, int v_off, int s_off = 0) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v_off, s_off, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v_off, s_off, AUX));
 }
 __device__ __forceinline__ f16x8 bufld8h(__amdgpu_buffer_rsrc_t r, int v_off, int s_off = 0) {
     return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, v_off, s_off, 0));
 }
+template <int AUX = 0>
 __device__ __forceinline__ f32x2 bufld2(__amdgpu_buffer_rsrc_t r, int v_off, int s_off = 0) {
-    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, v_off, s_off, 0));
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, v_off, s_off, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ float bufld1(__amdgpu_buffer_rsrc_t r, int v_off, int s_off = 0) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, v_off, s_off, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, v_off, s_off, AUX));
 }
 __device__ __forceinline__ void bufst4(__amdgpu_buffer_rsrc_t r, int v_off, int s_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, v_off, s_off, 0);
@@ -257,10 +263,22 @@ __device__ __forceinline__ f32x4 gld4(const void* base, unsigned v_off, unsigned
 __device__ __forceinline__ void gst4(void* base, unsigned v_off, unsigned s_off, f32x4 v) {
     *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + s_off + (size_t)v_off) = v;
 }
+// write-through form (global_store ... sc1): the line goes to memory now and is dropped from this XCD's L2 instead of staying dirty until
+// the end-of-kernel write-back (MI355X_MICROARCH.md "boundary": + dirty bytes / 6 TB/s behind a kernel that leaves them; "stores of each
+// flavour": a 16-byte sc1 store costs what a plain one does). For data nobody reads before the next launch: the new state and the next
+// layer's records (76 MB per launch at 24 k atoms) - same box 1,862 -> 1,913 structures/s, nn = 8 -5.7 % per launch, the others -2 %
+// (profiles/r06_writethrough_ab.txt). Inline asm: no builtin emits
+// the cache-policy bits on a plain global store; the trailing s_nop covers the store-data hazard the compiler cannot see.
+__device__ __forceinline__ void gst4_wt(void* base, unsigned v_off, unsigned s_off, f32x4 v) {
+    const char* b = reinterpret_cast<const char*>(base) + s_off;
+    // (s_nop 4 in front: the SGPR pair may have just been reloaded from a spill lane by v_readlane - VALU writes SGPR -> VMEM reads it needs
+    //  five wait states, and the hazard recogniser does not look inside inline asm: without it the store went to a stale base and faulted)
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(v_off), "v"(v), "s"(b));
+}
 __device__ __forceinline__ void gst4_finite(void* base, unsigned v_off, unsigned s_off, f32x4 v) {      // see st4_finite
     constexpr float M = 3.0e38f;
-    gst4(base, v_off, s_off, f32x4{__builtin_amdgcn_fmed3f(v[0], -M, M), __builtin_amdgcn_fmed3f(v[1], -M, M), __builtin_amdgcn_fmed3f(v[2], -M, M),
-                                   __builtin_amdgcn_fmed3f(v[3], -M, M)});
+    gst4_wt(base, v_off, s_off, f32x4{__builtin_amdgcn_fmed3f(v[0], -M, M), __builtin_amdgcn_fmed3f(v[1], -M, M), __builtin_amdgcn_fmed3f(v[2], -M, M),
+                                            __builtin_amdgcn_fmed3f(v[3], -M, M)});
 }
 __device__ __forceinline__ void bufst4_finite(__amdgpu_buffer_rsrc_t r, int v_off, int s_off, f32x4 v) {      // see st4_finite
     constexpr float M = 3.0e38f;

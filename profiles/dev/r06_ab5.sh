@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 6: write-through (sc1) record / state stores A/B (wt0 plain, wt1 records, wt2 records + state) with a parity check of wt2
+mkdir -p gpurun_out/r06h
+PESTO_LIB=$PWD/pesto_amd/csrc/libpesto_hip_wt2.so timeout 600 python -m pytest tests/test_hip_parity.py -m gpu -q -x -k "golden or config5 or odd_launch or forced_edge or determinism or batch_independent" 2>&1 | tail -4 | cut -c1-300 > gpurun_out/r06h/pytest_wt2.txt
+rm -rf gpurun_out/ab; bash profiles/ab.sh "$@"
+python profiles/ab_show.py > gpurun_out/r06h/ab.txt
+cat gpurun_out/r06h/pytest_wt2.txt gpurun_out/r06h/ab.txt
