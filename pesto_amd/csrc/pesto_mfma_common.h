@@ -275,6 +275,14 @@ __device__ __forceinline__ void gst4_wt(void* base, unsigned v_off, unsigned s_o
     //  five wait states, and the hazard recogniser does not look inside inline asm: without it the store went to a stale base and faulted)
     asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(v_off), "v"(v), "s"(b));
 }
+__device__ __forceinline__ void st4_wt(float* p, f32x4 v) {      // the same with a per-lane 64-bit address (k_node16)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v));
+}
+__device__ __forceinline__ void st4_wt_finite(float* p, f32x4 v) {
+    constexpr float M = 3.0e38f;
+    st4_wt(p, f32x4{__builtin_amdgcn_fmed3f(v[0], -M, M), __builtin_amdgcn_fmed3f(v[1], -M, M), __builtin_amdgcn_fmed3f(v[2], -M, M),
+                    __builtin_amdgcn_fmed3f(v[3], -M, M)});
+}
 __device__ __forceinline__ void gst4_finite(void* base, unsigned v_off, unsigned s_off, f32x4 v) {      // see st4_finite
     constexpr float M = 3.0e38f;
     gst4_wt(base, v_off, s_off, f32x4{__builtin_amdgcn_fmed3f(v[0], -M, M), __builtin_amdgcn_fmed3f(v[1], -M, M), __builtin_amdgcn_fmed3f(v[2], -M, M),

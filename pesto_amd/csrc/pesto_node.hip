@@ -340,8 +340,8 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
             if (valid) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (ob < 8) st4_finite(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);
-                    else st4(nb + (ob + j - 8) * 16 + 4 * g, a[j]);                   // A_j[16 fb + 4g + r]
+                    if (ob < 8) st4_wt_finite(cen + (ob + j) * 64 + 3 * 16 + 4 * g, a[j]);      // (write-through: 63 MB per launch must not sit dirty in L2 at the kernel boundary)
+                    else st4_wt(nb + (ob + j - 8) * 16 + 4 * g, a[j]);                   // A_j[16 fb + 4g + r]
                 }
             }
         }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) st4_finite(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
+                    for (int c = 0; c < 3; ++c) st4_wt_finite(cen + (ob + j) * 64 + c * 16 + 4 * g, a[j][c]);
             }
         }
         if (role == 3) {   // node queries Q = nqm(X_n): 64 -> 32 -> 32 -> 12                        (:119)
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(NODE_WAVES * 64, 1) void k_node16(const float* __re
             split8(elu4(t[0]), elu4(t[1]), xh, xl);
             mfma16_multi<1>(Lnq + 3072, 0, 1, 0, lane, xh, xl, qq);
             sat_probe(sat, qq[0][0]);
-            if (valid) st4(cen + 512 + 4 * g, qq[0]);
+            if (valid) st4_wt(cen + 512 + 4 * g, qq[0]);
         }
         if (valid) sat_flush_at(sat, flags, i);      // (this lane's probes cover MFMA column e = atom i of the tile)
         sat = 0.0f;
