@@ -285,6 +285,13 @@ __device__ __forceinline__ void prio_by_age(int cls) {
         else __builtin_amdgcn_s_setprio(P2);
     }
 }
+#ifdef PESTO_DEV_TIMELINE      // developer build (profiles/dev/timeline.py): wall-clock stamps (100 MHz) of every workgroup of the first 64 layer launches
+__device__ unsigned long long g_tl[64][256][16];
+__device__ int g_tl_launch;
+#define PESTO_TL(k) { if ((threadIdx.x & 63) == 0 && tl_l < 64 && blockIdx.x < 256) g_tl[tl_l][blockIdx.x][k] = wall_clock64(); }
+#else
+#define PESTO_TL(k) {}
+#endif
 // Two families of instantiations: F16 = true, the shipped f16-split kernels (hybrid first layer HY, finish / prepare phase inside FIN,
 // 8- or 12-wave workgroups); F16 = false, the exact fp32 kernels (4-wave workgroups, explicit cross-tile prefetch PF, Z through memory).
 template <int NN, int WPB, bool F16, int TI = 4, int NE = WPB>
@@ -310,6 +317,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
     static_assert(NE == WPB || (FIN && WPB - NE == 4 && NE * A * SUBS == 16), "node waves: four of them, one 16-centre tile per iteration");
     __shared__ EdgeSmem<WPB, HY, FIN, NE> sm;
     if (threadIdx.x < 8) sm.xflag[threadIdx.x] = 0;
+#ifdef PESTO_DEV_TIMELINE
+    const int tl_l = F16 ? *(volatile int*)&g_tl_launch : 64;
+    if (threadIdx.x == 0) PESTO_TL(0)
+#endif
     // The edge rows (neighbour id, geometry) of the wave's FIRST work item are requested before the layer constants are staged, so that
     // their round trip runs under that copy instead of behind the workgroup barrier - a small launch (one structure) is one or two
     // items per wave deep and pays every such latency in full (one-structure forward: see DESIGN 4.1f).
@@ -349,6 +360,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
         ws0.geo[2][l0] = first_valid ? first_geo.z : 0.f; ws0.geo[3][l0] = first_valid ? first_geo.w : 0.f; ws0.geo[4][l0] = 1.0f;
     }
     __syncthreads();
+#ifdef PESTO_DEV_TIMELINE
+    if (threadIdx.x == 0) PESTO_TL(1)
+#endif
     const EdgeBufs eb{make_rsrc(rec_nb), make_rsrc(rec_cen), make_rsrc(p_state)};
     const float* w2f = sm.w + EL_W2F;
     const float* w3k = sm.w + EL_W3K;
@@ -1297,6 +1311,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? 2 : WPB / 4) void k_edge(const
       }
     }
     if (F16) sat_flush(sat + sat_b, flags);      // (nothing is left here: every probe has been flushed with its centre)
+#ifdef PESTO_DEV_TIMELINE
+    if (threadIdx.x == 0) { PESTO_TL(2) if (blockIdx.x == 0 && F16) atomicAdd(&g_tl_launch, 1); }
+    if (threadIdx.x == 64 * 7) PESTO_TL(4)
+#endif
 }
 
 // =============================================================================================== launchers
@@ -1410,3 +1428,16 @@ void launch_edge(hipStream_t st, const float* W, const LayerW& lw, int N1, const
 }
 
 }  // namespace pesto
+
+#ifdef PESTO_DEV_TIMELINE
+// developer build only: copies the stamps out (out: 64 x 256 x 8 uint64) and rewinds the launch counter; returns the launches seen
+extern "C" int pesto_dev_timeline(unsigned long long* out) {
+    int n = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(pesto::g_tl_launch), sizeof(int));
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pesto::g_tl), sizeof(unsigned long long) * 64 * 256 * 16);
+    const int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pesto::g_tl_launch), &zero, sizeof(int));
+    return n;
+}
+#endif
