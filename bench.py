@@ -789,7 +789,19 @@ def run(args, stage):
         seg_call = {"call": "Model.forward_segments(X, ids_topk, q, res_of_atom, R): the dense mask reduced by the caller (not in the timed region)",
                     "mask_bytes_not_read": int(n_atoms_total) * int(R) * 4, "steps": n_sig, "ms_per_step": t_sig * 1e3,
                     "structures_per_s": args.batch / t_sig, "bitwise_equal_to_the_headline_call": bool(torch.equal(zs, z)),
-                    "mask_pass_ms_per_step": elapsed / args.steps * 1e3 - t_sig * 1e3}
+                    "step_minus_this_step_ms": elapsed / args.steps * 1e3 - t_sig * 1e3}
+        # the mask pass by itself: HIP events around n_sig reductions of the resident mask on the stream the forward runs on (the difference of
+        # the two timed legs above is smaller than their run-to-run spread)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        model._segments(Md)
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(n_sig):
+            model._segments(Md)
+        ev[1].record()
+        torch.cuda.synchronize()
+        seg_call["mask_pass_ms_per_step"] = ev[0].elapsed_time(ev[1]) / n_sig
+        seg_call["mask_pass_GBps"] = int(n_atoms_total) * int(R) * 4 / (seg_call["mask_pass_ms_per_step"] * 1e-3) / 1e9
 
     # ---- side measurement: batch-1 latency (ms per structure when structures arrive one at a time)
     lat_ms = lat_detail = None
