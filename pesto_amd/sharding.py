@@ -362,7 +362,7 @@ def _bind_to_node_of(bdf, info, sysfs="/sys", set_omp=True, max_threads=None):
         return info
     try:
         cpus = set(_parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read()))
-    except OSError as e:
+    except (OSError, ValueError) as e:
         info["why"] = f"no cpulist of node {node}: {e}"
         return info
     if hasattr(os, "sched_getaffinity"):
