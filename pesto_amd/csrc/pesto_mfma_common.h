@@ -43,8 +43,19 @@ __device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
 #ifdef PESTO_ABL_NOSPLIT   // ablation: no residual (results wrong): -8 VALU per eight values
         lo[j] = h[0]; lo[j + 1] = h[1];
 #else
+#ifdef PESTO_SPLIT_MIXLO      // rounds 1 - 5: one v_fma_mix{lo,hi}_f16 per element (2.48 issue units each)
         lo[j] = (_Float16)__builtin_fmaf((float)h[0], m1, v[j]);
         lo[j + 1] = (_Float16)__builtin_fmaf((float)h[1], m1, v[j + 1]);
+#else
+        // the residuals in fp32 (v_fma_mix_f32 reads the f16 halves directly: 1.34 units each; x - hi is exact in fp32), then ONE
+        // v_cvt_pk_f16_f32 for the pair: 5.0 instead of 6.1 issue units per pair (profiles/microbench/r06_valu_cost.txt), the same single
+        // rounding to f16 - same bits. (opaque: the compiler would fuse fptrunc(fma(fpext)) back into the f16-destination forms)
+        float r0 = __builtin_fmaf((float)h[0], m1, v[j]), r1 = __builtin_fmaf((float)h[1], m1, v[j + 1]);
+        asm("" : "+v"(r0));
+        asm("" : "+v"(r1));
+        const f16x2 l = __builtin_convertvector(f32x2{r0, r1}, f16x2);
+        lo[j] = l[0]; lo[j + 1] = l[1];
+#endif
 #endif
     }
 }

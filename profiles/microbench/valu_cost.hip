@@ -47,6 +47,13 @@ KERNEL(k_mulf,     "v_mul_f32 %[f0], %[f0], %[f2]\n v_mul_f32 %[f1], %[f1], %[f3
 KERNEL(k_max,      "v_max_f32 %[f0], %[f0], %[f2]\n v_max_f32 %[f1], %[f1], %[f3]\n")
 KERNEL(k_pkmul,    "v_pk_mul_f32 %[p0], %[p0], %[p1]\n v_pk_add_f32 %[p1], %[p1], %[p0]\n")
 KERNEL(k_pkaddf16, "v_pk_add_f16 %[f0], %[f0], %[f2]\n v_pk_fma_f16 %[f1], %[f1], %[f2], %[f3]\n")
+// round 6: the f16 hi/lo split and its alternatives (f2, f3 = the two fp32 inputs of a pair; results in f0 / f1)
+KERNEL(k_mixlo_nodep, "v_fma_mixlo_f16 %[f0], %[f2], %[f3], %[f3] op_sel_hi:[0,0,0]\n v_fma_mixhi_f16 %[f1], %[f2], %[f3], %[f3] op_sel_hi:[0,0,0]\n")
+KERNEL(k_mix_f32,  "v_fma_mix_f32 %[f0], %[f2], %[f3], %[f0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %[f1], %[f2], %[f3], %[f1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n")
+KERNEL(k_cvt_f32_f16, "v_cvt_f32_f16 %[f0], %[f2]\n v_cvt_f32_f16_sdwa %[f1], %[f3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n")
+KERNEL(k_split_cur, "v_cvt_pk_f16_f32 %[f0], %[f2], %[f3]\n v_fma_mixlo_f16 %[f1], %[f0], -1.0, %[f2] op_sel_hi:[1,0,0]\n v_fma_mixhi_f16 %[f1], %[f0], -1.0, %[f3] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n")
+KERNEL(k_split_mixf32, "v_cvt_pk_f16_f32 %[f0], %[f2], %[f3]\n v_fma_mix_f32 %[i0], %[f0], -1.0, %[f2] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %[f1], %[f0], -1.0, %[f3] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_cvt_pk_f16_f32 %[f1], %[i0], %[f1]\n")
+KERNEL(k_split_cvt, "v_cvt_pk_f16_f32 %[f0], %[f2], %[f3]\n v_cvt_f32_f16 %[i0], %[f0]\n v_cvt_f32_f16_sdwa %[f1], %[f0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_sub_f32 %[i0], %[f2], %[i0]\n v_sub_f32 %[f1], %[f3], %[f1]\n v_cvt_pk_f16_f32 %[f1], %[i0], %[f1]\n")
 typedef void (*kern_t)(int, float*);
 static double run(kern_t k, float* d) {
     const int iters = 20000;
@@ -64,5 +71,8 @@ int main() {
 #define SHOW(k) { const double t = run(k, d); printf("%-14s %6.3f ns per instruction per SIMD   x%.2f of v_fma_f32\n", #k, t, t / base); }
     SHOW(k_fma) SHOW(k_pkfma) SHOW(k_pkmul) SHOW(k_exp) SHOW(k_exp_fma) SHOW(k_exp_3fma) SHOW(k_rcp) SHOW(k_med3) SHOW(k_cvtpk) SHOW(k_mixlo) SHOW(k_mad64) SHOW(k_lshladd64)
     SHOW(k_addu32) SHOW(k_mul24) SHOW(k_mullo) SHOW(k_movdpp) SHOW(k_adddpp) SHOW(k_readlane) SHOW(k_cndmask) SHOW(k_cndmask_s) SHOW(k_cndmask_d) SHOW(k_and) SHOW(k_bfi) SHOW(k_mulf) SHOW(k_max) SHOW(k_pkaddf16)
+    SHOW(k_mixlo_nodep) SHOW(k_mix_f32) SHOW(k_cvt_f32_f16)
+    printf("-- sequences per PAIR of values (ns per instruction; x instructions = per pair): split_cur 3 instr, split_mixf32 4, split_cvt 6\n");
+    SHOW(k_split_cur) SHOW(k_split_mixf32) SHOW(k_split_cvt)
     return 0;
 }
