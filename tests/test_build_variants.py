@@ -6,6 +6,7 @@ The timing-only ablations kept in the tree (results WRONG by construction; profi
   PESTO_ABL_NOPREPST  the prepare phase's record stores alias           PESTO_ABL_NONODE    the node waves only keep their queues moving
   PESTO_ABL_NOPREP    no prepare phase at all (pesto_api.hip)
 and one instrument (results unchanged): PESTO_DEV_TIMELINE - wall-clock stamps of every workgroup of a layer launch (profiles/dev/timeline.py)
+and one A/B form (same bits): PESTO_SPLIT_MIXLO - the f16 hi/lo split's residual as v_fma_mix{lo,hi}_f16 per element, as shipped until round 5
 Checked with `hipcc -fsyntax-only` for gfx950 (semantic analysis instantiates every kernel template the launchers use): seconds per
 macro, no GPU. Also: no OTHER `PESTO_*` preprocessor switch is left in the layer-kernel sources."""
 import os
@@ -22,7 +23,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 LAYER_SOURCES = ["pesto_edge.hip", "pesto_node.hip", "pesto_mfma_common.h", "pesto_fin_rendezvous.inc", "pesto_edge_node_waves.inc"]
 ABLATIONS = {"PESTO_ABL_NOSPLIT": "pesto_edge.hip", "PESTO_ABL_NOELU": "pesto_edge.hip", "PESTO_ABL_NOGATHER": "pesto_edge.hip",
              "PESTO_ABL_NOCENLD": "pesto_edge.hip", "PESTO_ABL_NOPREPST": "pesto_edge.hip", "PESTO_ABL_NONODE": "pesto_edge.hip",
-             "PESTO_ABL_NOPREP": "pesto_api.hip", "PESTO_DEV_TIMELINE": "pesto_edge.hip"}
+             "PESTO_ABL_NOPREP": "pesto_api.hip", "PESTO_DEV_TIMELINE": "pesto_edge.hip", "PESTO_SPLIT_MIXLO": "pesto_edge.hip"}
 
 
 def _syntax(source, *defines):
@@ -40,7 +41,7 @@ def test_every_kept_ablation_compiles(macro):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_all_edge_ablations_together_and_the_node_file():
-    p = _syntax("pesto_edge.hip", *[m for m, s in ABLATIONS.items() if s == "pesto_edge.hip" and m != "PESTO_DEV_TIMELINE"])
+    p = _syntax("pesto_edge.hip", *[m for m, s in ABLATIONS.items() if s == "pesto_edge.hip" and m.startswith("PESTO_ABL_")])
     assert p.returncode == 0, p.stderr[-1500:]
     p = _syntax("pesto_node.hip", "PESTO_ABL_NOSPLIT", "PESTO_ABL_NOELU")
     assert p.returncode == 0, p.stderr[-1500:]
