@@ -30,7 +30,7 @@ torch.cuda.synchronize()
 n = fn(buf.ctypes.data)
 nns = [l["nn"] for l in cfg["sum"]]
 print(f"launches seen {n}; times in us (10 ns stamps), mean over the workgroups of a launch unless said otherwise")
-chain = {}; acc = {}; by_xcd = {}; in_xcd = {}; by_jb = {}
+rdv = {}; chain = {}; acc = {}; by_xcd = {}; in_xcd = {}; by_jb = {}
 for l in range(min(n, 64)):
     t = buf[l].astype(np.int64)
     on = t[:, 0] > 0
@@ -38,7 +38,8 @@ for l in range(min(n, 64)):
         continue
     t = t[on]
     t0 = t[:, 0].min()
-    nodew = (t[:, 3] > 0).all()
+    rendezvous = (t[:, 15] > 0).all()      # (slot 15 = wave 11's arrival at a rendezvous: node-wave kernels never write it)
+    nodew = not rendezvous and (t[:, 3] > 0).all()
     item_end = np.maximum(t[:, 2], t[:, 4])
     end = np.maximum(item_end, np.maximum(t[:, 3], t[:, 5])) if nodew else item_end
     row = {"wgs": int(on.sum()), "span": (end.max() - t0) / 100.0, "entry_spread": (t[:, 0].max() - t0) / 100.0, "prologue": (t[:, 1] - t[:, 0]).mean() / 100.0,
@@ -46,6 +47,11 @@ for l in range(min(n, 64)):
            "first_wg_end": (end.min() - t0) / 100.0, "last_wg_end": (end.max() - t0) / 100.0, "mean_wg_end": (end.mean() - t0) / 100.0}
     nn = nns[l] if l < len(nns) else 0
     acc.setdefault(nn, []).append(row)
+    if rendezvous:      # rendezvous mode: arrivals of the twelve waves at the LAST rendezvous, release seen by wave 0
+        arr = t[:, 4:16]
+        last = arr.max(axis=1)
+        rdv.setdefault(nn, []).append([((last[:, None] - arr).mean() / 100.0), ((last - arr.min(axis=1)).mean() / 100.0), ((t[:, 3] - last).mean() / 100.0),
+                                       ((last[:, None] - arr).reshape(len(arr), 3, 4).mean(axis=(0, 1)) / 100.0).tolist()])
     if nodew:      # the LAST tile of node waves role 0 / role 1, relative to the moment the last item wave left
         ie = item_end
         chain.setdefault(nn, []).append([((t[:, k] - ie).mean() / 100.0) for k in (6, 7, 8, 9, 10, 3, 11, 12, 13, 14, 5)])
@@ -64,3 +70,7 @@ for nn in sorted(chain):
     v = np.mean(chain[nn], axis=0)
     print(f"nn = {nn:2d} last tile, us after the last item wave left: role 0 loop top {v[0]:5.1f} rows {v[1]:5.1f} state done {v[2]:5.1f} inputs {v[3]:5.1f} [U|A] done {v[4]:5.1f} end {v[5]:5.1f} | "
           f"role 1 loop top {v[6]:5.1f} rows {v[7]:5.1f} state + G done {v[8]:5.1f} inputs {v[9]:5.1f} end {v[10]:5.1f}")
+for nn in sorted(rdv):
+    v = rdv[nn]
+    print(f"nn = {nn:2d} last rendezvous: a wave waits {np.mean([r[0] for r in v]):5.2f} us on average for the last of its workgroup (first to last arrival {np.mean([r[1] for r in v]):5.2f} us; "
+          f"release seen {np.mean([r[2] for r in v]):4.2f} us after the last arrival); by SIMD (wave % 4): " + " ".join(f"{x:5.2f}" for x in np.mean([r[3] for r in v], axis=0)))
