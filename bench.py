@@ -647,17 +647,21 @@ def run(args, stage):
                                "neighbour terms of layer 1 are VALU work there) and k_node, / time by HIP events / the 157.3 TF fp32 MFMA peak")
 
     # ---- roofline leg: HIP events around the state-update launches, on the stream they run on
+    # (each sample = the LAST of three back-to-back steps: its events are recorded into a busy stream, as in the timed region of the headline;
+    #  a step that starts on a drained GPU reads ~1 % longer)
     model.set_timing(True)
     lay_ms = []
     for _ in range(max(5, min(args.steps, 20))):
-        step()
+        for _ in range(3):
+            step()
         torch.cuda.synchronize()
         lay_ms.append(model.get_timing())
     # per-kernel pass (one event between consecutive layer launches): average launch duration of every kernel class
     model.set_timing(True, per_kernel=True)
     per_kernel = []
     for _ in range(5):
-        step()
+        for _ in range(3):
+            step()
         torch.cuda.synchronize()
         per_kernel.append(model.get_kernel_timing())
     model.set_timing(False)
