@@ -766,16 +766,41 @@ def run(args, stage):
     if not args.no_extras:
         n_long = max(200, args.steps)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_long + 1)]
+        # the clock and the package power THIS box holds under the workload (the stamped roofline.clock_GHz is the profile box's): amdsmi's
+        # current gfx clock / socket power through torch, sampled by a host thread while the 200 steps run (boxes of the pool differ by
+        # several per cent in the clock they hold at the 1,400 W cap - VERDICT r5 weak item 4)
+        import threading
+        live, stop = [], threading.Event()
+
+        def sampler():
+            while not stop.is_set():
+                try:
+                    live.append((float(torch.cuda.clock_rate(dev)), float(torch.cuda.power_draw(dev))))
+                except Exception:      # noqa: BLE001 - no amdsmi on this host: the keys stay null
+                    return
+                time.sleep(0.004)
+        th = threading.Thread(target=sampler, daemon=True)
         barrier()
+        th.start()
         evs[0].record()
         for i in range(n_long):
             step()
             evs[i + 1].record()
         torch.cuda.synchronize()
+        stop.set()
+        th.join(timeout=2.0)
         dt = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_long)])
+        live_clock = None
+        if len(live) >= 8:
+            lv = np.array(live[len(live) // 4:])      # (the first quarter: the queue is still filling)
+            pw = lv[:, 1] / (1000.0 if np.median(lv[:, 1]) > 5000.0 else 1.0)
+            live_clock = {"sclk_GHz_mean": float(lv[:, 0].mean() / 1e3), "sclk_GHz_min_max": [float(lv[:, 0].min() / 1e3), float(lv[:, 0].max() / 1e3)],
+                          "power_W_mean": float(pw.mean()), "samples": int(len(lv)),
+                          "how": "torch.cuda.clock_rate() / power_draw() (amdsmi) every 4 ms from a host thread during the 200-step sample; the mean "
+                                 "over the forward's kernel mix (k_edge<64> holds less, k_edge<8> more)"}
         long_sample = {"steps": n_long, "ms_per_step_median": float(np.median(dt)), "ms_per_step_p10": float(np.percentile(dt, 10)),
                        "ms_per_step_p90": float(np.percentile(dt, 90)), "ms_per_step_mean": float(dt.mean()),
-                       "structures_per_s_from_median": args.batch / float(np.median(dt)) * 1e3,
+                       "structures_per_s_from_median": args.batch / float(np.median(dt)) * 1e3, "live_clock": live_clock,
                        "how": "HIP events between consecutive steps on torch's current stream (the stream the kernels are launched on)"}
 
     # ---- the same forward with the mask pre-reduced by the caller (forward_segments: res_of_atom instead of M); until round 5 the headline

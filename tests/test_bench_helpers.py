@@ -57,7 +57,8 @@ def test_per_nn_table_and_rocprof_fraction():
     table, _ = bench.per_nn_table(cfg, kern, n1, tf)
     assert table["64"]["clock_GHz"] == 2.16 and abs(table["64"]["issue_floor_ratio"] - 270.5 / 241.8) < 1e-9 and table["8"]["issue_floor_ratio"] is None
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for key in ('"hbm_actual_frac"', '"issue_floor_ratio"', '"clock_GHz"', '"frac_of_fp32_mfma_peak"', '"bound_note"', '"segment_call"', '"call": "Model.forward(X, ids_topk, q, M)"'):
+    for key in ('"hbm_actual_frac"', '"issue_floor_ratio"', '"clock_GHz"', '"frac_of_fp32_mfma_peak"', '"bound_note"', '"segment_call"', '"call": "Model.forward(X, ids_topk, q, M)"',
+                '"live_clock"', '"sclk_GHz_mean"', '"mask_pass_ms_per_step"'):
         assert key in src, key
     assert 'else "issue"' in src      # neither pipe half used: the line says instruction issue binds, not hbm
     assert '"frac_rocprof"' in src and '"per_nn"' in src and "speedup_vs_reference_equivalent_cpu_estimate" in src
